@@ -1,0 +1,651 @@
+"""alice_codec_amd -- host-side mirror of the ALICE-Codec encode/decode API over the
+MI355X (gfx950) C-ABI library ``libalice_codec.so``.
+
+The names follow the reference's public surface (Rust ``src/pipeline.rs``,
+``src/wavelet.rs``, ``src/quant.rs``, ``src/rans.rs`` and its PyO3 module
+``src/python.rs:408-482``): ``FrameEncoder``, ``FrameDecoder``, ``EncodedChunk``,
+``WaveletType``, ``Wavelet1D/2D/3D``, ``Quantizer``, ``FastQuantizer``,
+``to_symbols`` / ``from_symbols`` / ``build_histogram``, ``FrequencyTable``,
+``RansEncoder`` / ``RansDecoder``.  Every call goes through the C ABI declared in
+``include/alice_codec.h`` and runs on the GPU.  There is no CPU fallback: when the
+library is missing or no HIP device is usable this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalice_codec.so")
+
+VERSION = "0.1.2"
+DEFAULT_CHUNK_SIZE = 64  # reference src/lib.rs:110
+
+
+class WaveletType(enum.IntEnum):  # reference src/pipeline.rs:34-41
+    Cdf53 = 0
+    Cdf97 = 1
+    Haar = 2
+
+
+class CodecError(Exception):
+    """Mirror of the reference ``CodecError`` (src/error.rs:12-23)."""
+
+    NAMES = {
+        1: "InvalidBufferSize", 2: "InvalidDimensions", 3: "DimensionOverflow", 4: "InvalidBitstream",
+        5: "InvalidQuantStep", 6: "ReferenceDiverges", 7: "OutOfMemory", 8: "DeviceError",
+        9: "NullArgument", 10: "Internal",
+    }
+
+    def __init__(self, code: int, message: str = ""):
+        self.code = code
+        self.kind = self.NAMES.get(code, f"Error{code}")
+        super().__init__(f"{self.kind}: {message}" if message else self.kind)
+
+
+_u8p = C.POINTER(C.c_uint8)
+_i16p = C.POINTER(C.c_int16)
+_u16p = C.POINTER(C.c_uint16)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libalice_codec.so (built in-tree by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is the product path and has no fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        "alice_codec_wavelet1d_haar": (vp, []),
+        "alice_codec_wavelet1d_cdf53": (vp, []),
+        "alice_codec_wavelet1d_cdf97": (vp, []),
+        "alice_codec_wavelet1d_destroy": (None, [vp]),
+        "alice_codec_wavelet1d_forward": (None, [vp, _i32p, C.c_uint32]),
+        "alice_codec_wavelet1d_inverse": (None, [vp, _i32p, C.c_uint32]),
+        "alice_codec_encoder_create": (vp, [C.c_uint8]),
+        "alice_codec_encoder_destroy": (None, [vp]),
+        "alice_codec_encode": (vp, [vp, _u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "alice_codec_decode": (vp, [vp, _u32p]),
+        "alice_codec_chunk_destroy": (None, [vp]),
+        "alice_codec_chunk_to_bytes": (vp, [vp, _u32p]),
+        "alice_codec_chunk_from_bytes": (vp, [_u8p, C.c_uint32]),
+        "alice_codec_chunk_width": (C.c_uint32, [vp]),
+        "alice_codec_chunk_height": (C.c_uint32, [vp]),
+        "alice_codec_chunk_frames": (C.c_uint32, [vp]),
+        "alice_codec_psnr": (C.c_double, [_u8p, _u8p, C.c_uint32]),
+        "alice_codec_data_free": (None, [vp, C.c_uint32]),
+        "alice_codec_string_free": (None, [vp]),
+        "alice_codec_version": (vp, []),
+        # extensions
+        "alice_codec_last_error": (C.c_int, []),
+        "alice_codec_last_error_message": (C.c_char_p, []),
+        "alice_codec_device_count": (C.c_int, []),
+        "alice_codec_set_device": (C.c_int, [C.c_int]),
+        "alice_codec_trim": (None, []),
+        "alice_codec_encoder_create_ex": (vp, [C.c_uint8, C.c_uint8]),
+        "alice_codec_encoder_quality": (C.c_uint8, [vp]),
+        "alice_codec_encoder_wavelet": (C.c_uint8, [vp]),
+        "alice_codec_chunk_wavelet": (C.c_uint8, [vp]),
+        "alice_codec_chunk_compressed_size": (C.c_uint64, [vp]),
+        "alice_codec_encode64": (vp, [vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "alice_codec_decode64": (vp, [vp, _u64p]),
+        "alice_codec_chunk_to_bytes64": (vp, [vp, _u64p]),
+        "alice_codec_chunk_from_bytes64": (vp, [_u8p, C.c_uint64]),
+        "alice_codec_data_free64": (None, [vp, C.c_uint64]),
+        "alice_codec_batch_create": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8]),
+        "alice_codec_batch_destroy": (None, [vp]),
+        "alice_codec_batch_encode": (C.c_int, [vp, vp, vp]),
+        "alice_codec_batch_encode_finish": (C.c_int, [vp, _u64p]),
+        "alice_codec_batch_alc_ptr": (vp, [vp, C.c_uint32]),
+        "alice_codec_batch_alc_stride": (C.c_uint64, [vp]),
+        "alice_codec_batch_decode": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+        "alice_codec_batch_decode_finish": (C.c_int, [vp]),
+        "alice_codec_batch_stage_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "alice_codec_batch_symbols_ptr": (vp, [vp]),
+        "alice_codec_batch_padded_pixels": (C.c_uint64, [vp]),
+        "alice_codec_wavelet2d_forward": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64]),
+        "alice_codec_wavelet2d_inverse": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64]),
+        "alice_codec_wavelet3d_forward": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64, C.c_uint64]),
+        "alice_codec_wavelet3d_inverse": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64, C.c_uint64]),
+        "alice_codec_quantize_buffer": (C.c_int, [C.c_int32, C.c_int32, _i32p, C.c_uint64, _i32p, C.c_uint64]),
+        "alice_codec_dequantize_buffer": (C.c_int, [C.c_int32, _i32p, C.c_uint64, _i32p, C.c_uint64]),
+        "alice_codec_fastquant_new": (vp, [C.c_int32]),
+        "alice_codec_fastquant_with_dead_zone": (vp, [C.c_int32, C.c_int32]),
+        "alice_codec_fastquant_destroy": (None, [vp]),
+        "alice_codec_fastquant_step": (C.c_int32, [vp]),
+        "alice_codec_fastquant_dead_zone": (C.c_int32, [vp]),
+        "alice_codec_fastquant_quantize_buffer": (C.c_int, [vp, _i32p, C.c_uint64, _i32p, C.c_uint64]),
+        "alice_codec_fastquant_dequantize_buffer": (C.c_int, [vp, _i32p, C.c_uint64, _i32p, C.c_uint64]),
+        "alice_codec_to_symbols": (C.c_int, [_i32p, C.c_uint64, _u8p, C.c_uint64]),
+        "alice_codec_from_symbols": (C.c_int, [_u8p, C.c_uint64, _i32p, C.c_uint64]),
+        "alice_codec_build_histogram": (C.c_int, [_u8p, C.c_uint64, _u32p]),
+        "alice_codec_freq_table_from_histogram": (C.c_int, [_u32p, _u16p, _u16p]),
+        "alice_codec_rans_encode": (vp, [_u8p, C.c_uint64, _u16p, _u16p, _u64p]),
+        "alice_codec_rans_decode": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
+        "alice_codec_rgb_to_ycocg_r": (C.c_int, [_u8p, C.c_uint64, _i16p, _i16p, _i16p, C.c_uint64]),
+        "alice_codec_ycocg_r_to_rgb": (C.c_int, [_i16p, _i16p, _i16p, C.c_uint64, _u8p, C.c_uint64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS_PART1 = [
+    "alice_codec_wavelet1d_haar", "alice_codec_wavelet1d_cdf53", "alice_codec_wavelet1d_cdf97",
+    "alice_codec_wavelet1d_destroy", "alice_codec_wavelet1d_forward", "alice_codec_wavelet1d_inverse",
+    "alice_codec_encoder_create", "alice_codec_encoder_destroy", "alice_codec_encode", "alice_codec_decode",
+    "alice_codec_chunk_destroy", "alice_codec_chunk_to_bytes", "alice_codec_chunk_from_bytes",
+    "alice_codec_chunk_width", "alice_codec_chunk_height", "alice_codec_chunk_frames", "alice_codec_psnr",
+    "alice_codec_data_free", "alice_codec_string_free", "alice_codec_version",
+]
+
+
+def _raise_last(default_code: int = 10):
+    lib = load_library()
+    code = lib.alice_codec_last_error() or default_code
+    msg = lib.alice_codec_last_error_message()
+    raise CodecError(code, msg.decode("utf-8", "replace") if msg else "")
+
+
+def _check(rc: int):
+    if rc != 0:
+        _raise_last(rc)
+
+
+def _as_u8(a) -> np.ndarray:
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        return np.frombuffer(a, dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def device_count() -> int:
+    return load_library().alice_codec_device_count()
+
+
+def set_device(i: int) -> None:
+    _check(load_library().alice_codec_set_device(i))
+
+
+def version() -> str:
+    lib = load_library()
+    p = lib.alice_codec_version()
+    try:
+        return C.string_at(p).decode()
+    finally:
+        lib.alice_codec_string_free(p)
+
+
+# ---------------------------------------------------------------------------------------------
+# pipeline
+# ---------------------------------------------------------------------------------------------
+
+class EncodedChunk:
+    """reference src/pipeline.rs:172-313 (handle owned by the library)."""
+
+    def __init__(self, handle: int):
+        if not handle:
+            raise ValueError("null chunk handle")
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.alice_codec_chunk_destroy(h)
+
+    @property
+    def width(self) -> int:
+        return load_library().alice_codec_chunk_width(self._h)
+
+    @property
+    def height(self) -> int:
+        return load_library().alice_codec_chunk_height(self._h)
+
+    @property
+    def frames(self) -> int:
+        return load_library().alice_codec_chunk_frames(self._h)
+
+    @property
+    def wavelet_type(self) -> WaveletType:
+        return WaveletType(load_library().alice_codec_chunk_wavelet(self._h))
+
+    def compressed_size(self) -> int:
+        return load_library().alice_codec_chunk_compressed_size(self._h)
+
+    def to_bytes(self) -> bytes:
+        lib = load_library()
+        n = C.c_uint64()
+        p = lib.alice_codec_chunk_to_bytes64(self._h, C.byref(n))
+        if not p:
+            _raise_last()
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            lib.alice_codec_data_free64(p, n.value)
+
+    @staticmethod
+    def from_bytes(data) -> "EncodedChunk":
+        lib = load_library()
+        d = _as_u8(data)
+        h = lib.alice_codec_chunk_from_bytes64(_p(d, _u8p) if d.size else C.cast(C.c_char_p(b""), _u8p), d.size)
+        if not h:
+            _raise_last(4)
+        return EncodedChunk(h)
+
+
+class FrameEncoder:
+    """reference src/pipeline.rs:335-507.  ``FrameEncoder(q)`` = ``new``; ``with_wavelet`` as in the reference."""
+
+    def __init__(self, quality: int, wavelet_type: WaveletType = WaveletType.Cdf53):
+        lib = load_library()
+        self.quality = int(quality) & 0xFF
+        self.wavelet_type = WaveletType(wavelet_type)
+        self._h = lib.alice_codec_encoder_create_ex(self.quality, int(self.wavelet_type))
+        if not self._h:
+            _raise_last()
+
+    @classmethod
+    def with_wavelet(cls, quality: int, wavelet_type: WaveletType) -> "FrameEncoder":
+        return cls(quality, wavelet_type)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.alice_codec_encoder_destroy(h)
+
+    def encode(self, rgb_frames, width: int, height: int, frames: int) -> EncodedChunk:
+        lib = load_library()
+        r = _as_u8(rgb_frames)
+        for v in (width, height, frames):
+            if not 0 <= v <= 0xFFFFFFFF:
+                raise CodecError(3, "dimension out of u32 range")
+        ptr = _p(r, _u8p) if r.size else C.cast(C.c_char_p(b""), _u8p)
+        h = lib.alice_codec_encode64(self._h, ptr, r.size, width, height, frames)
+        if not h:
+            _raise_last()
+        return EncodedChunk(h)
+
+
+class FrameDecoder:
+    """reference src/pipeline.rs:519-631."""
+
+    def decode(self, chunk: EncodedChunk) -> np.ndarray:
+        lib = load_library()
+        n = C.c_uint64()
+        p = lib.alice_codec_decode64(chunk._h, C.byref(n))
+        if not p:
+            _raise_last()
+        try:
+            return np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy()
+        finally:
+            lib.alice_codec_data_free64(p, n.value)
+
+
+def psnr(a, b) -> float:
+    """metrics::psnr via the C ABI (src/ffi.rs:270-278): -1.0 on length mismatch."""
+    a, b = _as_u8(a), _as_u8(b)
+    if a.size != b.size:
+        return -1.0
+    z = C.cast(C.c_char_p(b""), _u8p)
+    return load_library().alice_codec_psnr(_p(a, _u8p) if a.size else z, _p(b, _u8p) if b.size else z, a.size)
+
+
+# ---------------------------------------------------------------------------------------------
+# wavelets
+# ---------------------------------------------------------------------------------------------
+
+class Wavelet1D:
+    """reference src/wavelet.rs:47-249 through the 6 drop-in FFI functions (src/ffi.rs:16-86)."""
+
+    def __init__(self, kind: WaveletType):
+        lib = load_library()
+        self.kind = WaveletType(kind)
+        ctor = {WaveletType.Cdf53: lib.alice_codec_wavelet1d_cdf53, WaveletType.Cdf97: lib.alice_codec_wavelet1d_cdf97,
+                WaveletType.Haar: lib.alice_codec_wavelet1d_haar}[self.kind]
+        self._h = ctor()
+
+    @classmethod
+    def cdf97(cls): return cls(WaveletType.Cdf97)
+
+    @classmethod
+    def cdf53(cls): return cls(WaveletType.Cdf53)
+
+    @classmethod
+    def haar(cls): return cls(WaveletType.Haar)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.alice_codec_wavelet1d_destroy(h)
+
+    def _run(self, signal, fn) -> np.ndarray:
+        s = np.array(signal, dtype=np.int32).reshape(-1).copy()
+        if s.size:
+            fn(self._h, _p(s, _i32p), s.size)
+            if load_library().alice_codec_last_error():
+                _raise_last()
+        return s
+
+    def forward(self, signal) -> np.ndarray:
+        return self._run(signal, load_library().alice_codec_wavelet1d_forward)
+
+    def inverse(self, signal) -> np.ndarray:
+        return self._run(signal, load_library().alice_codec_wavelet1d_inverse)
+
+
+class Wavelet2D:
+    """reference src/wavelet.rs:265-341."""
+
+    def __init__(self, kind: WaveletType = WaveletType.Cdf53):
+        self.kind = WaveletType(kind)
+
+    @classmethod
+    def cdf97(cls): return cls(WaveletType.Cdf97)
+
+    @classmethod
+    def cdf53(cls): return cls(WaveletType.Cdf53)
+
+    def forward(self, image, width: int, height: int) -> np.ndarray:
+        s = np.array(image, dtype=np.int32).reshape(-1).copy()
+        assert s.size == width * height
+        if s.size:
+            _check(load_library().alice_codec_wavelet2d_forward(int(self.kind), _p(s, _i32p), width, height))
+        return s
+
+    def inverse(self, image, width: int, height: int) -> np.ndarray:
+        s = np.array(image, dtype=np.int32).reshape(-1).copy()
+        assert s.size == width * height
+        if s.size:
+            _check(load_library().alice_codec_wavelet2d_inverse(int(self.kind), _p(s, _i32p), width, height))
+        return s
+
+
+class Wavelet3D:
+    """reference src/wavelet.rs:358-485."""
+
+    def __init__(self, kind: WaveletType = WaveletType.Cdf53):
+        self.kind = WaveletType(kind)
+
+    @classmethod
+    def cdf97(cls): return cls(WaveletType.Cdf97)
+
+    @classmethod
+    def cdf53(cls): return cls(WaveletType.Cdf53)
+
+    def forward(self, volume, width: int, height: int, depth: int) -> np.ndarray:
+        s = np.array(volume, dtype=np.int32).reshape(-1).copy()
+        assert s.size == width * height * depth
+        if s.size:
+            _check(load_library().alice_codec_wavelet3d_forward(int(self.kind), _p(s, _i32p), width, height, depth))
+        return s
+
+    def inverse(self, volume, width: int, height: int, depth: int) -> np.ndarray:
+        s = np.array(volume, dtype=np.int32).reshape(-1).copy()
+        assert s.size == width * height * depth
+        if s.size:
+            _check(load_library().alice_codec_wavelet3d_inverse(int(self.kind), _p(s, _i32p), width, height, depth))
+        return s
+
+
+# ---------------------------------------------------------------------------------------------
+# quantisers, symbols, histogram
+# ---------------------------------------------------------------------------------------------
+
+class Quantizer:
+    """reference src/quant.rs:57-153."""
+
+    def __init__(self, step: int, dead_zone: int | None = None):
+        self.step = int(step)
+        self.dead_zone = int(step if dead_zone is None else dead_zone)
+
+    @classmethod
+    def with_dead_zone(cls, step: int, dead_zone: int): return cls(step, dead_zone)
+
+    def quantize_buffer(self, values, out_len: int | None = None) -> np.ndarray:
+        v = np.ascontiguousarray(values, np.int32).reshape(-1)
+        out = np.zeros(v.size if out_len is None else out_len, np.int32)
+        _check(load_library().alice_codec_quantize_buffer(self.step, self.dead_zone, _p(v, _i32p), v.size, _p(out, _i32p), out.size))
+        return out
+
+    def dequantize_buffer(self, values, out_len: int | None = None) -> np.ndarray:
+        v = np.ascontiguousarray(values, np.int32).reshape(-1)
+        out = np.zeros(v.size if out_len is None else out_len, np.int32)
+        _check(load_library().alice_codec_dequantize_buffer(self.step, _p(v, _i32p), v.size, _p(out, _i32p), out.size))
+        return out
+
+    def quantize(self, value: int) -> int:
+        return int(self.quantize_buffer([value])[0])
+
+    def dequantize(self, q: int) -> int:
+        return int(self.dequantize_buffer([q])[0])
+
+
+class FastQuantizer:
+    """reference src/quant.rs:171-359."""
+
+    def __init__(self, step: int, dead_zone: int | None = None):
+        lib = load_library()
+        self._h = lib.alice_codec_fastquant_new(step) if dead_zone is None else lib.alice_codec_fastquant_with_dead_zone(step, dead_zone)
+        if not self._h:
+            _raise_last(5)
+
+    @classmethod
+    def with_dead_zone(cls, step: int, dead_zone: int): return cls(step, dead_zone)
+
+    @classmethod
+    def from_quantizer(cls, q: Quantizer): return cls(q.step, q.dead_zone)  # From<Quantizer>, :355-359
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.alice_codec_fastquant_destroy(h)
+
+    def step(self) -> int: return load_library().alice_codec_fastquant_step(self._h)
+
+    def dead_zone(self) -> int: return load_library().alice_codec_fastquant_dead_zone(self._h)
+
+    def quantize_buffer(self, values, out_len: int | None = None) -> np.ndarray:
+        v = np.ascontiguousarray(values, np.int32).reshape(-1)
+        out = np.zeros(v.size if out_len is None else out_len, np.int32)
+        _check(load_library().alice_codec_fastquant_quantize_buffer(self._h, _p(v, _i32p), v.size, _p(out, _i32p), out.size))
+        return out
+
+    quantize_buffer_simd = quantize_buffer  # :322-332 (same results by contract)
+
+    def dequantize_buffer(self, values, out_len: int | None = None) -> np.ndarray:
+        v = np.ascontiguousarray(values, np.int32).reshape(-1)
+        out = np.zeros(v.size if out_len is None else out_len, np.int32)
+        _check(load_library().alice_codec_fastquant_dequantize_buffer(self._h, _p(v, _i32p), v.size, _p(out, _i32p), out.size))
+        return out
+
+    def quantize(self, value: int) -> int: return int(self.quantize_buffer([value])[0])
+
+    def dequantize(self, q: int) -> int: return int(self.dequantize_buffer([q])[0])
+
+
+def to_symbols(coeffs, out_len: int | None = None) -> np.ndarray:
+    v = np.ascontiguousarray(coeffs, np.int32).reshape(-1)
+    out = np.zeros(v.size if out_len is None else out_len, np.uint8)
+    _check(load_library().alice_codec_to_symbols(_p(v, _i32p), v.size, _p(out, _u8p), out.size))
+    return out
+
+
+def from_symbols(symbols, out_len: int | None = None) -> np.ndarray:
+    s = _as_u8(symbols)
+    out = np.zeros(s.size if out_len is None else out_len, np.int32)
+    _check(load_library().alice_codec_from_symbols(_p(s, _u8p), s.size, _p(out, _i32p), out.size))
+    return out
+
+
+def build_histogram(symbols) -> np.ndarray:
+    s = _as_u8(symbols)
+    out = np.zeros(256, np.uint32)
+    z = C.cast(C.c_char_p(b""), _u8p)
+    _check(load_library().alice_codec_build_histogram(_p(s, _u8p) if s.size else z, s.size, _p(out, _u32p)))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# rANS
+# ---------------------------------------------------------------------------------------------
+
+class FrequencyTable:
+    """reference src/rans.rs:85-219 over the 256-symbol alphabet of the pipeline."""
+
+    def __init__(self, cum_freq: np.ndarray, freq: np.ndarray):
+        self.cum_freq = np.ascontiguousarray(cum_freq, np.uint16)
+        self.freq = np.ascontiguousarray(freq, np.uint16)
+
+    @classmethod
+    def from_histogram(cls, histogram) -> "FrequencyTable":
+        h = np.ascontiguousarray(histogram, np.uint32).reshape(-1)
+        if h.size != 256:
+            raise ValueError("the GPU path supports the pipeline's 256-bin histograms")
+        cum = np.zeros(256, np.uint16); fr = np.zeros(256, np.uint16)
+        _check(load_library().alice_codec_freq_table_from_histogram(_p(h, _u32p), _p(cum, _u16p), _p(fr, _u16p)))
+        return cls(cum, fr)
+
+    @classmethod
+    def uniform(cls, n_symbols: int = 256) -> "FrequencyTable":
+        if n_symbols != 256:
+            raise ValueError("the GPU path supports 256 symbols")
+        return cls.from_histogram(np.zeros(256, np.uint32))  # total == 0 -> uniform (src/rans.rs:106-109)
+
+    def __len__(self): return 256
+
+
+class RansEncoder:
+    """reference src/rans.rs:238-309: encode_symbols (reverse order) + finish."""
+
+    def __init__(self): self._pending = None
+
+    @classmethod
+    def with_capacity(cls, capacity: int): return cls()
+
+    def encode_symbols(self, symbols, table: FrequencyTable) -> None:
+        if self._pending is not None:
+            raise ValueError("one encode_symbols call per encoder on the GPU path")
+        self._pending = (_as_u8(symbols).copy(), table)
+
+    def finish(self) -> bytes:
+        lib = load_library()
+        sym, table = self._pending if self._pending is not None else (np.zeros(0, np.uint8), FrequencyTable.uniform())
+        n = C.c_uint64()
+        z = C.cast(C.c_char_p(b""), _u8p)
+        p = lib.alice_codec_rans_encode(_p(sym, _u8p) if sym.size else z, sym.size, _p(table.cum_freq, _u16p),
+                                        _p(table.freq, _u16p), C.byref(n))
+        if not p:
+            _raise_last()
+        try:
+            return C.string_at(p, n.value)
+        finally:
+            lib.alice_codec_data_free64(p, n.value)
+
+
+class RansDecoder:
+    """reference src/rans.rs:321-389: new + decode_n."""
+
+    def __init__(self, data): self._data = _as_u8(data).copy()
+
+    def decode_n(self, n: int, table: FrequencyTable) -> np.ndarray:
+        out = np.zeros(n, np.uint8)
+        z = C.cast(C.c_char_p(b""), _u8p)
+        _check(load_library().alice_codec_rans_decode(_p(self._data, _u8p) if self._data.size else z, self._data.size,
+                                                      _p(table.cum_freq, _u16p), _p(table.freq, _u16p), n,
+                                                      _p(out, _u8p) if n else z))
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# colour
+# ---------------------------------------------------------------------------------------------
+
+def rgb_bytes_to_ycocg_r(rgb):
+    r = _as_u8(rgb)
+    n = r.size // 3
+    y = np.zeros(n, np.int16); co = np.zeros(n, np.int16); cg = np.zeros(n, np.int16)
+    z = C.cast(C.c_char_p(b""), _u8p)
+    _check(load_library().alice_codec_rgb_to_ycocg_r(_p(r, _u8p) if r.size else z, r.size, _p(y, _i16p), _p(co, _i16p), _p(cg, _i16p), n))
+    return y, co, cg
+
+
+def ycocg_r_to_rgb_bytes(y, co, cg) -> np.ndarray:
+    y = np.ascontiguousarray(y, np.int16); co = np.ascontiguousarray(co, np.int16); cg = np.ascontiguousarray(cg, np.int16)
+    if not (y.size == co.size == cg.size):
+        raise CodecError(1, "channel lengths differ")
+    out = np.zeros(y.size * 3, np.uint8)
+    _check(load_library().alice_codec_ycocg_r_to_rgb(_p(y, _i16p), _p(co, _i16p), _p(cg, _i16p), y.size, _p(out, _u8p), out.size))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident batches (inputs/outputs are device pointers, e.g. torch tensors' data_ptr())
+# ---------------------------------------------------------------------------------------------
+
+class Batch:
+    """n_chunks equal-shaped chunks encoded/decoded entirely in HBM (alice_codec_batch_*)."""
+
+    def __init__(self, width: int, height: int, frames: int, n_chunks: int, quality: int,
+                 wavelet_type: WaveletType = WaveletType.Cdf53):
+        lib = load_library()
+        self.width, self.height, self.frames, self.n_chunks = width, height, frames, n_chunks
+        self._h = lib.alice_codec_batch_create(width, height, frames, n_chunks, quality, int(wavelet_type))
+        if not self._h:
+            _raise_last()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.alice_codec_batch_destroy(h)
+
+    def encode(self, d_rgb_ptr: int, stream: int = 0) -> None:
+        _check(load_library().alice_codec_batch_encode(self._h, d_rgb_ptr, stream))
+
+    def encode_finish(self) -> np.ndarray:
+        sizes = np.zeros(self.n_chunks, np.uint64)
+        _check(load_library().alice_codec_batch_encode_finish(self._h, _p(sizes, _u64p)))
+        return sizes
+
+    def alc_ptr(self, chunk: int = 0) -> int:
+        return load_library().alice_codec_batch_alc_ptr(self._h, chunk)
+
+    @property
+    def alc_stride(self) -> int:
+        return load_library().alice_codec_batch_alc_stride(self._h)
+
+    def decode(self, d_alc_ptr: int, alc_stride: int, d_rgb_out_ptr: int, stream: int = 0) -> None:
+        _check(load_library().alice_codec_batch_decode(self._h, d_alc_ptr, alc_stride, d_rgb_out_ptr, stream))
+
+    def decode_finish(self) -> None:
+        _check(load_library().alice_codec_batch_decode_finish(self._h))
+
+    def stage_ms(self) -> dict:
+        out = (C.c_float * 6)()
+        load_library().alice_codec_batch_stage_ms(self._h, out)
+        keys = ["forward_transform", "rans_table", "rans_encode", "assemble", "rans_decode", "inverse_transform"]
+        return dict(zip(keys, [float(v) for v in out]))
+
+    def symbols_ptr(self) -> int:
+        return load_library().alice_codec_batch_symbols_ptr(self._h)
+
+    @property
+    def padded_pixels(self) -> int:
+        return load_library().alice_codec_batch_padded_pixels(self._h)

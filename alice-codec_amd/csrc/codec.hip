@@ -1,0 +1,1079 @@
+// Host side of libalice_codec.so: device/stream/memory plumbing, the chunk object and
+// `.alc` (de)serialiser, the FrameEncoder / FrameDecoder orchestration and the C ABI
+// declared in include/alice_codec.h.
+//
+// Reference behaviour restated (reference checkout, file:line):
+//   FrameEncoder::encode   src/pipeline.rs:377-507     FrameDecoder::decode  src/pipeline.rs:537-624
+//   EncodedChunk::to_bytes src/pipeline.rs:200-226     from_bytes            src/pipeline.rs:235-313
+//   C ABI                  src/ffi.rs:12-315
+//
+// Every compute step is a HIP kernel; nothing here falls back to the CPU.  If no HIP
+// device is usable the entry points fail (NULL / error code) -- loudly via
+// alice_codec_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/alice_codec.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace alice;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+thread_local int tl_err = kOk;
+thread_local std::string tl_msg;
+
+int fail(int code, const std::string& msg) {
+    tl_err = code;
+    tl_msg = msg;
+    return code;
+}
+void clear_error() { tl_err = kOk; tl_msg.clear(); }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            int code__ = (e__ == hipErrorOutOfMemory) ? (int)kOutOfMemory : (int)kDeviceError; \
+            return fail(code__, std::string(#expr) + ": " + hipGetErrorString(e__));         \
+        }                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device, stream, memory pool
+// ------------------------------------------------------------------------------------------
+
+thread_local int tl_device = -1;         // -1: not chosen yet (device 0 on first use)
+thread_local hipStream_t tl_stream = nullptr;
+thread_local int tl_stream_device = -1;
+
+int ensure_device() {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(kDeviceError, "no usable HIP device: this library has no CPU fallback (" +
+                                      std::string(e != hipSuccess ? hipGetErrorString(e) : "device count 0") + ")");
+    if (tl_device < 0) {
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) tl_device = cur; else tl_device = 0;
+    }
+    if (tl_device >= count) return fail(kDeviceError, "device index out of range");
+    HIP_TRY(hipSetDevice(tl_device));
+    return kOk;
+}
+
+int get_stream(hipStream_t* out) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (!tl_stream || tl_stream_device != tl_device) {
+        HIP_TRY(hipStreamCreateWithFlags(&tl_stream, hipStreamNonBlocking));
+        tl_stream_device = tl_device;
+    }
+    *out = tl_stream;
+    return kOk;
+}
+
+// Size-bucketed cache of device allocations (hipMalloc/hipFree are synchronising and slow).
+class DevicePool {
+public:
+    int alloc(size_t bytes, void** out) {
+        const size_t b = bucket(bytes);
+        int dev = tl_device;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto it = free_.find({dev, b});
+            if (it != free_.end() && !it->second.empty()) {
+                *out = it->second.back();
+                it->second.pop_back();
+                cached_ -= b;
+                return kOk;
+            }
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, b);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(&p, b);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(kOutOfMemory, "hipMalloc of " + std::to_string(b) + " bytes failed: " + hipGetErrorString(e));
+        }
+        *out = p;
+        return kOk;
+    }
+    void release(void* p, size_t bytes) {
+        if (!p) return;
+        const size_t b = bucket(bytes);
+        std::lock_guard<std::mutex> g(mu_);
+        if (cached_ + b > kMaxCached) { (void)hipFree(p); return; }
+        free_[{tl_device, b}].push_back(p);
+        cached_ += b;
+    }
+    void trim() {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto& kv : free_) for (void* p : kv.second) (void)hipFree(p);
+        free_.clear();
+        cached_ = 0;
+    }
+private:
+    static size_t bucket(size_t bytes) {
+        if (bytes < 256) bytes = 256;
+        if (bytes <= (1u << 20)) {  // next power of two
+            size_t b = 256;
+            while (b < bytes) b <<= 1;
+            return b;
+        }
+        const size_t g = size_t(2) << 20;  // 2 MiB granules
+        return (bytes + g - 1) / g * g;
+    }
+    static constexpr size_t kMaxCached = size_t(8) << 30;
+    std::mutex mu_;
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_;
+    size_t cached_ = 0;
+};
+
+DevicePool& pool() {
+    static DevicePool* p = new DevicePool();  // leaked on purpose: no HIP calls during static destruction
+    return *p;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { reset(); }
+    int alloc(size_t bytes) {
+        reset();
+        if (bytes == 0) bytes = 16;
+        int rc = pool().alloc(bytes, &p);
+        if (rc == kOk) n = bytes;
+        return rc;
+    }
+    void reset() { if (p) pool().release(p, n); p = nullptr; n = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+#define TRY(expr) do { int rc__ = (expr); if (rc__ != kOk) return rc__; } while (0)
+
+// ------------------------------------------------------------------------------------------
+// chunk object and .alc (de)serialisation
+// ------------------------------------------------------------------------------------------
+
+struct ChannelHeader {            // reference src/pipeline.rs:123-134
+    uint32_t compressed_len = 0;
+    int32_t quant_step = 1;
+    int32_t quant_dead_zone = 1;
+    uint32_t num_symbols = 0;
+    uint32_t histogram[256] = {0};
+};
+
+}  // namespace
+
+struct EncodedChunk {             // reference src/pipeline.rs:172-185
+    uint32_t width = 0, height = 0, frames = 0;
+    uint8_t wavelet = kCdf53;
+    ChannelHeader ch[3];
+    std::vector<uint8_t> data;    // Y || Co || Cg streams
+};
+struct FrameEncoder { uint8_t quality; uint8_t wavelet; };
+struct Wavelet1D { int kind; };
+struct FastQuantizer { uint64_t reciprocal; uint32_t shift; int32_t step; int32_t dead_zone; };
+
+namespace {
+
+inline void put_u32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+inline uint32_t get_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// src/pipeline.rs:200-226
+void chunk_to_bytes(const EncodedChunk& c, std::vector<uint8_t>& out) {
+    out.resize((size_t)kAlcHeaderBytes + c.data.size());
+    uint8_t* p = out.data();
+    memcpy(p, "ALCC", 4);
+    p[4] = 1;
+    p[5] = c.wavelet;
+    put_u32(p + 6, c.width); put_u32(p + 10, c.height); put_u32(p + 14, c.frames);
+    size_t off = kFixedHeaderBytes;
+    for (int k = 0; k < 3; ++k) {
+        put_u32(p + off, c.ch[k].compressed_len); off += 4;
+        put_u32(p + off, (uint32_t)c.ch[k].quant_step); off += 4;
+        put_u32(p + off, (uint32_t)c.ch[k].quant_dead_zone); off += 4;
+        put_u32(p + off, c.ch[k].num_symbols); off += 4;
+        for (int i = 0; i < 256; ++i) { put_u32(p + off, c.ch[k].histogram[i]); off += 4; }
+    }
+    if (!c.data.empty()) memcpy(p + off, c.data.data(), c.data.size());
+}
+
+// header part of src/pipeline.rs:235-313; *payload_len = sum of compressed_len
+int parse_alc_header(const uint8_t* data, uint64_t len, EncodedChunk& c, uint64_t* payload_len) {
+    if (len < kAlcHeaderBytes)
+        return fail(kInvalidBitstream, "data too short: " + std::to_string(len) + " bytes (minimum 3138)");
+    if (memcmp(data, "ALCC", 4) != 0) return fail(kInvalidBitstream, "bad magic (expected ALCC)");
+    if (data[4] != 1) return fail(kInvalidBitstream, "unsupported version: " + std::to_string((int)data[4]) + " (expected 1)");
+    if (data[5] > 2) return fail(kInvalidBitstream, "unknown wavelet type byte: " + std::to_string((int)data[5]));
+    c.wavelet = data[5];
+    c.width = get_u32(data + 6); c.height = get_u32(data + 10); c.frames = get_u32(data + 14);
+    size_t off = kFixedHeaderBytes;
+    uint64_t total = 0;
+    for (int k = 0; k < 3; ++k) {
+        c.ch[k].compressed_len = get_u32(data + off); off += 4;
+        c.ch[k].quant_step = (int32_t)get_u32(data + off); off += 4;
+        c.ch[k].quant_dead_zone = (int32_t)get_u32(data + off); off += 4;
+        c.ch[k].num_symbols = get_u32(data + off); off += 4;
+        for (int i = 0; i < 256; ++i) { c.ch[k].histogram[i] = get_u32(data + off); off += 4; }
+        total += c.ch[k].compressed_len;
+    }
+    *payload_len = total;
+    return kOk;
+}
+
+int chunk_from_bytes(const uint8_t* data, uint64_t len, EncodedChunk& c) {
+    uint64_t total = 0;
+    TRY(parse_alc_header(data, len, c, &total));
+    if (len < (uint64_t)kAlcHeaderBytes + total)
+        return fail(kInvalidBitstream, "truncated payload: need " + std::to_string(kAlcHeaderBytes + total - len) + " more bytes");
+    c.data.assign(data + kAlcHeaderBytes, data + kAlcHeaderBytes + total);
+    return kOk;
+}
+
+// src/pipeline.rs:67-71
+int checked_pixel_count(uint64_t w, uint64_t h, uint64_t f, uint64_t* out) {
+    unsigned __int128 v = (unsigned __int128)w * h;
+    if (v > UINT64_MAX) return fail(kDimensionOverflow, "dimensions overflow usize");
+    v *= f;
+    if (v > UINT64_MAX) return fail(kDimensionOverflow, "dimensions overflow usize");
+    *out = (uint64_t)v;
+    return kOk;
+}
+
+// ------------------------------------------------------------------------------------------
+// encode / decode on device buffers
+// ------------------------------------------------------------------------------------------
+
+inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// Rigorous magnitude bound through the inverse 3-D lifting: true when 32-bit products are safe.
+bool inverse_fast_ok(int wavelet, const int32_t step[3]) {
+    const LiftSteps ls = lift_steps(wavelet);
+    long double worst = 0;
+    for (int c = 0; c < 3; ++c) {
+        long double a = 128.0L * fabsl((long double)step[c]);
+        if (a > worst) worst = a;
+    }
+    long double m = worst;  // bound on every sample
+    for (int pass = 0; pass < 3; ++pass) {
+        long double me = m, mo = m;
+        for (int k = ls.n - 1; k >= 0; --k) {
+            const long double cabs = fabsl((long double)ls.coeff[k]);
+            long double& target = (k & 1) == 0 ? mo : me;
+            const long double other = (k & 1) == 0 ? me : mo;
+            if (2 * other * cabs + 4096 >= 2147483647.0L) return false;
+            target = target + (2 * other * cabs + 4096) / 8192 + 1;
+            if (target >= 1073741824.0L) return false;
+        }
+        m = me > mo ? me : mo;
+    }
+    return true;
+}
+
+struct EncodeWork {
+    ChunkDims d{};
+    int n_chunks = 0;
+    uint64_t cap = 0, alc_stride = 0;
+    DevBuf mid, tmp, sym, hist, tables, streams, results, alc, sizes, planes;
+};
+
+int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks, uint64_t cap) {
+    w.d = d; w.n_chunks = n_chunks; w.cap = cap;
+    w.alc_stride = round_up((uint64_t)kAlcHeaderBytes + 3 * cap, 256);
+    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
+    TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
+    TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
+    TRY(w.tables.alloc((size_t)n_chunks * 3 * sizeof(RansTable)));
+    TRY(w.streams.alloc((size_t)n_chunks * 3 * cap));
+    TRY(w.results.alloc((size_t)n_chunks * 3 * sizeof(RansResult)));
+    TRY(w.alc.alloc((size_t)n_chunks * w.alc_stride));
+    TRY(w.sizes.alloc((size_t)n_chunks * sizeof(unsigned long long)));
+    return kOk;
+}
+
+uint64_t default_cap(const ChunkDims& d) { return round_up(d.padded + d.padded / 4 + 4096, 256); }
+uint64_t worst_cap(const ChunkDims& d) { return round_up(2 * d.padded + 4 + 64, 256); }
+
+// Exact reference arithmetic on caller-shaped data for chunks of more than 64 padded frames.
+int forward_generic(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step, EncodeWork& w,
+                    uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
+    if (!w.planes.p) TRY(w.planes.alloc(3 * d.n_pixels * sizeof(int16_t)));
+    if (!w.tmp.p) TRY(w.tmp.alloc(d.padded * sizeof(int32_t)));
+    int16_t* pl = w.planes.as<int16_t>();
+    launch_rgb_to_ycocg(d_rgb, d.n_pixels, pl, pl + d.n_pixels, pl + 2 * d.n_pixels, st);
+    int32_t* vol = w.mid.as<int32_t>();
+    int32_t* qb = vol + d.padded;
+    const uint64_t W = d.pw, H = d.ph, D = d.pf;
+    for (int c = 0; c < 3; ++c) {
+        launch_pad_channel(pl + (size_t)c * d.n_pixels, d, vol, st);
+        launch_wavelet_axis(vol, w.tmp.as<int32_t>(), W, 1, D * H, W, 1, 0, wavelet, false, st);
+        launch_wavelet_axis(vol, w.tmp.as<int32_t>(), H, W, D, W * H, W, 1, wavelet, false, st);
+        launch_wavelet_axis(vol, w.tmp.as<int32_t>(), D, W * H, 1, 0, W * H, 1, wavelet, false, st);
+        launch_quantize(vol, qb, d.padded, step, step, st);
+        launch_to_symbols(qb, d_sym + (size_t)c * d.padded, d.padded, st);
+        launch_histogram(d_sym + (size_t)c * d.padded, d.padded, d_hist + c * 256, st);
+    }
+    return kOk;
+}
+
+struct StageEvents {
+    hipEvent_t ev[8] = {nullptr};
+    bool ready = false;
+    int init() {
+        if (ready) return kOk;
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        ready = true;
+        return kOk;
+    }
+    ~StageEvents() { if (ready) for (auto& e : ev) (void)hipEventDestroy(e); }
+};
+
+// Launches the whole encode of n_chunks chunks on `st`; results stay on the device.
+int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wavelet, hipStream_t st,
+                  StageEvents* evs) {
+    const ChunkDims& d = w.d;
+    const int32_t step = quality_to_step(quality);
+    const int B = w.n_chunks;
+    HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)B * 3 * 256 * sizeof(uint32_t), st));
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[0], st));
+    for (int b = 0; b < B; ++b) {
+        const uint8_t* rgb = d_rgb + (size_t)b * d.n_pixels * 3;
+        uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
+        uint32_t* hist = w.hist.as<uint32_t>() + (size_t)b * 3 * 256;
+        if (!launch_forward_transform(rgb, d, wavelet, step, w.mid.as<int32_t>(), sym, hist, st))
+            TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
+    }
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[1], st));
+    launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[2], st));
+    launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.streams.as<uint8_t>(),
+                       w.cap, w.results.as<RansResult>(), 3 * B, st);
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[3], st));
+    launch_write_headers(w.alc.as<uint8_t>(), w.alc_stride, d, wavelet, step, w.hist.as<uint32_t>(),
+                         w.results.as<RansResult>(), w.sizes.as<unsigned long long>(), B, st);
+    launch_compact_streams(w.alc.as<uint8_t>(), w.alc_stride, w.streams.as<uint8_t>(), w.cap,
+                           w.results.as<RansResult>(), B, st);
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[4], st));
+    HIP_TRY(hipGetLastError());
+    return kOk;
+}
+
+// After the stream has drained: fetch per-chain results, map flags to errors.
+int encode_collect(EncodeWork& w, hipStream_t st, std::vector<RansResult>& res) {
+    res.resize((size_t)w.n_chunks * 3);
+    HIP_TRY(hipMemcpyAsync(res.data(), w.results.p, res.size() * sizeof(RansResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (auto& r : res) {
+        if (r.flags & kTableDiverges)
+            return fail(kReferenceDiverges, "a symbol whose table frequency wrapped to 0 is present: the reference encoder does not terminate on this input");
+        if (r.flags & kRansInternal) return fail(kInternal, "rANS kernel invariant violated");
+    }
+    for (auto& r : res)
+        if (r.flags & kRansOverflow) return -1;  // caller retries with the worst-case capacity
+    return kOk;
+}
+
+struct DecodeWork {
+    ChunkDims d{};
+    int n_chunks = 0;
+    DevBuf mid, tmp, sym, hist, tables, descs, results, planes, vol;
+};
+
+int decode_work_alloc(DecodeWork& w, const ChunkDims& d, int n_chunks) {
+    w.d = d; w.n_chunks = n_chunks;
+    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
+    TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
+    TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
+    TRY(w.tables.alloc((size_t)n_chunks * 3 * sizeof(RansTable)));
+    TRY(w.descs.alloc((size_t)n_chunks * 3 * sizeof(RansDecodeDesc)));
+    TRY(w.results.alloc((size_t)n_chunks * 3 * sizeof(RansResult)));
+    return kOk;
+}
+
+int inverse_generic(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3], DecodeWork& w,
+                    uint8_t* d_rgb, hipStream_t st) {
+    if (!w.planes.p) TRY(w.planes.alloc(3 * d.n_pixels * sizeof(int16_t)));
+    if (!w.tmp.p) TRY(w.tmp.alloc(d.padded * sizeof(int32_t)));
+    int16_t* pl = w.planes.as<int16_t>();
+    int32_t* qb = w.mid.as<int32_t>();
+    int32_t* vol = qb + d.padded;
+    const uint64_t W = d.pw, H = d.ph, D = d.pf;
+    for (int c = 0; c < 3; ++c) {
+        launch_from_symbols(d_sym + (size_t)c * d.padded, qb, d.padded, st);
+        launch_dequantize(qb, vol, d.padded, step[c], st);
+        launch_wavelet_axis(vol, w.tmp.as<int32_t>(), D, W * H, 1, 0, W * H, 1, wavelet, true, st);
+        launch_wavelet_axis(vol, w.tmp.as<int32_t>(), H, W, D, W * H, W, 1, wavelet, true, st);
+        launch_wavelet_axis(vol, w.tmp.as<int32_t>(), W, 1, D * H, W, 1, 0, wavelet, true, st);
+        launch_strip_channel(vol, d, pl + (size_t)c * d.n_pixels, st);
+    }
+    launch_ycocg_to_rgb(pl, pl + d.n_pixels, pl + 2 * d.n_pixels, d.n_pixels, d_rgb, st);
+    return kOk;
+}
+
+// headers[b]: parsed chunk headers (validated); d_payload[b]: device pointer to chunk b's payload
+int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<const uint8_t*>& d_payload,
+                  DecodeWork& w, uint8_t* d_rgb_out, hipStream_t st, StageEvents* evs) {
+    const ChunkDims& d = w.d;
+    const int B = w.n_chunks;
+    std::vector<uint32_t> hist((size_t)B * 3 * 256);
+    std::vector<RansDecodeDesc> descs((size_t)B * 3);
+    for (int b = 0; b < B; ++b) {
+        uint64_t off = 0;
+        for (int c = 0; c < 3; ++c) {
+            const ChannelHeader& h = headers[b].ch[c];
+            memcpy(&hist[((size_t)b * 3 + c) * 256], h.histogram, 256 * sizeof(uint32_t));
+            RansDecodeDesc& ds = descs[(size_t)b * 3 + c];
+            ds.in = d_payload[b] + off;
+            ds.in_len = h.compressed_len;
+            ds.out = w.sym.as<uint8_t>() + ((size_t)b * 3 + c) * d.padded;
+            ds.n = d.padded;
+            ds.table = w.tables.as<RansTable>() + ((size_t)b * 3 + c);
+            off += h.compressed_len;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(w.hist.p, hist.data(), hist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w.descs.p, descs.data(), descs.size() * sizeof(RansDecodeDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[5], st));
+    launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
+    launch_rans_decode(w.descs.as<RansDecodeDesc>(), w.results.as<RansResult>(), 3 * B, st);
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[6], st));
+    for (int b = 0; b < B; ++b) {
+        int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
+        const bool exact = !inverse_fast_ok(headers[b].wavelet, step);
+        const uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
+        uint8_t* rgb = d_rgb_out + (size_t)b * d.n_pixels * 3;
+        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, exact, w.mid.as<int32_t>(), rgb, st))
+            TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, rgb, st));
+    }
+    if (evs) HIP_TRY(hipEventRecord(evs->ev[7], st));
+    HIP_TRY(hipGetLastError());
+    return kOk;
+}
+
+int decode_collect(DecodeWork& w, hipStream_t st) {
+    std::vector<RansResult> res((size_t)w.n_chunks * 3);
+    HIP_TRY(hipMemcpyAsync(res.data(), w.results.p, res.size() * sizeof(RansResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (auto& r : res)
+        if (r.flags & kRansInternal) return fail(kInternal, "rANS decode table invariant violated");
+    return kOk;
+}
+
+// src/pipeline.rs:537-579 validation, in the reference's order
+int validate_for_decode(const EncodedChunk& c, ChunkDims* dims, uint64_t payload_len) {
+    uint64_t n_pixels = 0;
+    TRY(checked_pixel_count(c.width, c.height, c.frames, &n_pixels));
+    *dims = make_dims(c.width, c.height, c.frames);
+    if (n_pixels == 0) return kOk;
+    uint64_t off = 0;
+    for (int k = 0; k < 3; ++k) {
+        if ((uint64_t)c.ch[k].num_symbols != dims->padded)
+            return fail(kInvalidBitstream, "channel " + std::to_string(k) + ": num_symbols " + std::to_string(c.ch[k].num_symbols) +
+                                               " != padded_pixels " + std::to_string(dims->padded));
+        if (off + c.ch[k].compressed_len > payload_len)
+            return fail(kInvalidBitstream, "channel " + std::to_string(k) + ": compressed data overrun");
+        off += c.ch[k].compressed_len;
+    }
+    return kOk;
+}
+
+// FrameEncoder::encode on host buffers (src/pipeline.rs:377-507)
+int encode_host(const FrameEncoder& enc, const uint8_t* rgb, uint64_t rgb_len, uint32_t width, uint32_t height,
+                uint32_t frames, EncodedChunk& out) {
+    uint64_t n_pixels = 0;
+    TRY(checked_pixel_count(width, height, frames, &n_pixels));                 // :388
+    out.width = width; out.height = height; out.frames = frames; out.wavelet = enc.wavelet;
+    for (auto& h : out.ch) h = ChannelHeader();
+    out.data.clear();
+    if (n_pixels == 0) {                                                         // :391-412
+        if (rgb_len != 0) return fail(kInvalidBufferSize, "buffer size mismatch: expected 0, got " + std::to_string(rgb_len));
+        return kOk;
+    }
+    if (width == 0 || height == 0) return fail(kInvalidDimensions, "invalid dimensions");  // :415-417
+    if (n_pixels > UINT64_MAX / 3) return fail(kDimensionOverflow, "dimensions overflow usize");
+    if (rgb_len != n_pixels * 3)                                                // :422-427
+        return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n_pixels * 3) + ", got " + std::to_string(rgb_len));
+    const ChunkDims d = make_dims(width, height, frames);
+    if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count does not fit the header's u32 num_symbols");
+
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf d_rgb;
+    TRY(d_rgb.alloc(rgb_len));
+    HIP_TRY(hipMemcpyAsync(d_rgb.p, rgb, rgb_len, hipMemcpyHostToDevice, st));
+    EncodeWork w;
+    std::vector<RansResult> res;
+    uint64_t cap = default_cap(d);
+    for (int attempt = 0;; ++attempt) {
+        TRY(encode_work_alloc(w, d, 1, cap));
+        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr));
+        int rc = encode_collect(w, st, res);
+        if (rc == kOk) break;
+        if (rc != -1 || attempt > 0) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
+        cap = worst_cap(d);
+    }
+    uint64_t payload = res[0].len + res[1].len + res[2].len;
+    std::vector<uint8_t> alc((size_t)kAlcHeaderBytes + payload);
+    HIP_TRY(hipMemcpyAsync(alc.data(), w.alc.p, alc.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t tot = 0;
+    TRY(parse_alc_header(alc.data(), alc.size(), out, &tot));
+    if (tot != payload) return fail(kInternal, "device header/payload length mismatch");
+    out.data.assign(alc.begin() + kAlcHeaderBytes, alc.end());
+    return kOk;
+}
+
+// FrameDecoder::decode on a host chunk (src/pipeline.rs:537-624)
+int decode_host(const EncodedChunk& c, std::vector<uint8_t>& rgb) {
+    ChunkDims d;
+    TRY(validate_for_decode(c, &d, c.data.size()));
+    rgb.clear();
+    if (d.n_pixels == 0) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf d_payload, d_rgb;
+    TRY(d_payload.alloc(c.data.size() + 16));
+    TRY(d_rgb.alloc(d.n_pixels * 3));
+    if (!c.data.empty())
+        HIP_TRY(hipMemcpyAsync(d_payload.p, c.data.data(), c.data.size(), hipMemcpyHostToDevice, st));
+    DecodeWork w;
+    TRY(decode_work_alloc(w, d, 1));
+    std::vector<EncodedChunk> hdrs(1);
+    hdrs[0].width = c.width; hdrs[0].height = c.height; hdrs[0].frames = c.frames; hdrs[0].wavelet = c.wavelet;
+    for (int k = 0; k < 3; ++k) hdrs[0].ch[k] = c.ch[k];
+    std::vector<const uint8_t*> pay(1, d_payload.as<uint8_t>());
+    TRY(decode_launch(hdrs, pay, w, d_rgb.as<uint8_t>(), st, nullptr));
+    TRY(decode_collect(w, st));
+    rgb.resize(d.n_pixels * 3);
+    HIP_TRY(hipMemcpyAsync(rgb.data(), d_rgb.p, rgb.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+uint8_t* to_c_buffer(const std::vector<uint8_t>& v) {
+    uint8_t* p = (uint8_t*)malloc(v.size() ? v.size() : 1);
+    if (p && !v.empty()) memcpy(p, v.data(), v.size());
+    return p;
+}
+
+// generic staged run: copy in, run fn on device pointers, copy out
+template <typename Tin, typename Tout, typename Fn>
+int staged(const Tin* in, uint64_t n_in, Tout* out, uint64_t n_out, Fn fn) {
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf a, b;
+    TRY(a.alloc(n_in * sizeof(Tin)));
+    TRY(b.alloc(n_out * sizeof(Tout)));
+    if (n_in) HIP_TRY(hipMemcpyAsync(a.p, in, n_in * sizeof(Tin), hipMemcpyHostToDevice, st));
+    fn(a.as<Tin>(), b.as<Tout>(), st);
+    HIP_TRY(hipGetLastError());
+    if (n_out) HIP_TRY(hipMemcpyAsync(out, b.p, n_out * sizeof(Tout), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+int wavelet_nd(int kind, int32_t* data, uint64_t W, uint64_t H, uint64_t D, int ndim, bool inverse) {
+    if (!data) return fail(kNullArgument, "null data");
+    if (kind < 0 || kind > 2) return fail(kInvalidBitstream, "unknown wavelet type");
+    unsigned __int128 tot = (unsigned __int128)W * H * D;
+    if (tot > ((unsigned __int128)1 << 40)) return fail(kDimensionOverflow, "volume too large");
+    const uint64_t n = (uint64_t)tot;
+    if (n == 0) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf a, t;
+    TRY(a.alloc(n * 4));
+    TRY(t.alloc(n * 4));
+    HIP_TRY(hipMemcpyAsync(a.p, data, n * 4, hipMemcpyHostToDevice, st));
+    int32_t* v = a.as<int32_t>();
+    int32_t* tmp = t.as<int32_t>();
+    if (!inverse) {
+        launch_wavelet_axis(v, tmp, W, 1, D * H, W, 1, 0, kind, false, st);
+        if (ndim >= 2) launch_wavelet_axis(v, tmp, H, W, D, W * H, W, 1, kind, false, st);
+        if (ndim >= 3) launch_wavelet_axis(v, tmp, D, W * H, 1, 0, W * H, 1, kind, false, st);
+    } else {
+        if (ndim >= 3) launch_wavelet_axis(v, tmp, D, W * H, 1, 0, W * H, 1, kind, true, st);
+        if (ndim >= 2) launch_wavelet_axis(v, tmp, H, W, D, W * H, W, 1, kind, true, st);
+        launch_wavelet_axis(v, tmp, W, 1, D * H, W, 1, 0, kind, true, st);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(data, a.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// batches
+// ------------------------------------------------------------------------------------------
+
+struct AliceBatch {
+    ChunkDims d{};
+    uint32_t n_chunks = 0;
+    uint8_t quality = 0, wavelet = 0;
+    int device = 0;
+    EncodeWork enc;
+    DecodeWork dec;
+    bool dec_ready = false;
+    StageEvents evs;
+    hipStream_t enc_stream = nullptr, dec_stream = nullptr;
+    bool enc_timed = false, dec_timed = false;
+    float stage_ms[6] = {0, 0, 0, 0, 0, 0};
+};
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+
+extern "C" {
+
+// ---- PART 1: reference ABI ----
+
+Wavelet1D* alice_codec_wavelet1d_haar(void) { return new (std::nothrow) Wavelet1D{kHaar}; }
+Wavelet1D* alice_codec_wavelet1d_cdf53(void) { return new (std::nothrow) Wavelet1D{kCdf53}; }
+Wavelet1D* alice_codec_wavelet1d_cdf97(void) { return new (std::nothrow) Wavelet1D{kCdf97}; }
+void alice_codec_wavelet1d_destroy(Wavelet1D* ptr) { delete ptr; }
+
+void alice_codec_wavelet1d_forward(const Wavelet1D* w, int32_t* data, uint32_t len) {
+    if (!w || !data || len < 2) return;
+    clear_error();
+    (void)wavelet_nd(w->kind, data, len, 1, 1, 1, false);
+}
+void alice_codec_wavelet1d_inverse(const Wavelet1D* w, int32_t* data, uint32_t len) {
+    if (!w || !data || len < 2) return;
+    clear_error();
+    (void)wavelet_nd(w->kind, data, len, 1, 1, 1, true);
+}
+
+FrameEncoder* alice_codec_encoder_create(uint8_t quality) { return new (std::nothrow) FrameEncoder{quality, (uint8_t)kCdf53}; }
+void alice_codec_encoder_destroy(FrameEncoder* ptr) { delete ptr; }
+
+EncodedChunk* alice_codec_encode64(const FrameEncoder* encoder, const uint8_t* rgb, uint64_t rgb_len, uint32_t width,
+                                   uint32_t height, uint32_t frames) {
+    clear_error();
+    if (!encoder || !rgb) { fail(kNullArgument, "null argument"); return nullptr; }
+    EncodedChunk* c = new (std::nothrow) EncodedChunk();
+    if (!c) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    if (encode_host(*encoder, rgb, rgb_len, width, height, frames, *c) != kOk) { delete c; return nullptr; }
+    return c;
+}
+EncodedChunk* alice_codec_encode(const FrameEncoder* encoder, const uint8_t* rgb, uint32_t rgb_len, uint32_t width,
+                                 uint32_t height, uint32_t frames) {
+    return alice_codec_encode64(encoder, rgb, rgb_len, width, height, frames);
+}
+
+uint8_t* alice_codec_decode64(const EncodedChunk* chunk, uint64_t* out_len) {
+    clear_error();
+    if (!chunk || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
+    std::vector<uint8_t> rgb;
+    if (decode_host(*chunk, rgb) != kOk) return nullptr;
+    uint8_t* p = to_c_buffer(rgb);
+    if (!p) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    *out_len = rgb.size();
+    return p;
+}
+uint8_t* alice_codec_decode(const EncodedChunk* chunk, uint32_t* out_len) {
+    if (!chunk || !out_len) { clear_error(); fail(kNullArgument, "null argument"); return nullptr; }
+    uint64_t n = 0;
+    uint8_t* p = alice_codec_decode64(chunk, &n);
+    if (p) *out_len = (uint32_t)n;  // `rgb.len() as u32`, src/ffi.rs:157
+    return p;
+}
+
+void alice_codec_chunk_destroy(EncodedChunk* ptr) { delete ptr; }
+
+uint8_t* alice_codec_chunk_to_bytes64(const EncodedChunk* chunk, uint64_t* out_len) {
+    clear_error();
+    if (!chunk || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
+    std::vector<uint8_t> v;
+    chunk_to_bytes(*chunk, v);
+    uint8_t* p = to_c_buffer(v);
+    if (!p) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    *out_len = v.size();
+    return p;
+}
+uint8_t* alice_codec_chunk_to_bytes(const EncodedChunk* chunk, uint32_t* out_len) {
+    if (!chunk || !out_len) { clear_error(); fail(kNullArgument, "null argument"); return nullptr; }
+    uint64_t n = 0;
+    uint8_t* p = alice_codec_chunk_to_bytes64(chunk, &n);
+    if (p) *out_len = (uint32_t)n;
+    return p;
+}
+EncodedChunk* alice_codec_chunk_from_bytes64(const uint8_t* data, uint64_t len) {
+    clear_error();
+    if (!data) { fail(kNullArgument, "null argument"); return nullptr; }
+    EncodedChunk* c = new (std::nothrow) EncodedChunk();
+    if (!c) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    if (chunk_from_bytes(data, len, *c) != kOk) { delete c; return nullptr; }
+    return c;
+}
+EncodedChunk* alice_codec_chunk_from_bytes(const uint8_t* data, uint32_t len) { return alice_codec_chunk_from_bytes64(data, len); }
+
+uint32_t alice_codec_chunk_width(const EncodedChunk* c) { return c ? c->width : 0; }
+uint32_t alice_codec_chunk_height(const EncodedChunk* c) { return c ? c->height : 0; }
+uint32_t alice_codec_chunk_frames(const EncodedChunk* c) { return c ? c->frames : 0; }
+
+double alice_codec_psnr(const uint8_t* a, const uint8_t* b, uint32_t len) {
+    clear_error();
+    if (!a || !b) return -1.0;
+    if (len == 0) return INFINITY;  // mse 0.0 for empty buffers (src/metrics.rs:23-25)
+    hipStream_t st;
+    if (get_stream(&st) != kOk) return -1.0;
+    DevBuf da, db, ds;
+    if (da.alloc(len) || db.alloc(len) || ds.alloc(8)) return -1.0;
+    unsigned long long sum = 0;
+    if (hipMemcpyAsync(da.p, a, len, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(db.p, b, len, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(ds.p, 0, 8, st) != hipSuccess) { fail(kDeviceError, "copy failed"); return -1.0; }
+    launch_sq_diff_sum(da.as<uint8_t>(), db.as<uint8_t>(), len, ds.as<unsigned long long>(), st);
+    if (hipMemcpyAsync(&sum, ds.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { fail(kDeviceError, "psnr kernel failed"); return -1.0; }
+    // the reference sums squared differences in f64; every partial sum is an integer < 2^53, so the
+    // integer total converts to the same f64 (src/metrics.rs:26-34)
+    const double mse = (double)sum / (double)len;
+    if (mse == 0.0) return INFINITY;
+    return 10.0 * log10(255.0 * 255.0 / mse);
+}
+
+void alice_codec_data_free64(uint8_t* ptr, uint64_t len) { (void)len; if (ptr) free(ptr); }
+void alice_codec_data_free(uint8_t* ptr, uint32_t len) {
+    // reference: no-op when ptr is NULL or len == 0 (src/ffi.rs:289); our zero-length buffers are
+    // 1-byte mallocs, released here too so nothing leaks
+    (void)len;
+    if (ptr) free(ptr);
+}
+void alice_codec_string_free(char* s) { free(s); }
+char* alice_codec_version(void) {
+    const char* v = "0.1.2";  // CARGO_PKG_VERSION of the reference (Cargo.toml)
+    char* p = (char*)malloc(strlen(v) + 1);
+    if (p) strcpy(p, v);
+    return p;
+}
+
+// ---- PART 2: extensions ----
+
+int alice_codec_last_error(void) { return tl_err; }
+const char* alice_codec_last_error_message(void) { return tl_msg.c_str(); }
+int alice_codec_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int alice_codec_set_device(int device) {
+    clear_error();
+    int n = alice_codec_device_count();
+    if (device < 0 || device >= n) return fail(kDeviceError, "device index out of range");
+    tl_device = device;
+    return ensure_device();
+}
+void alice_codec_trim(void) { pool().trim(); }
+
+FrameEncoder* alice_codec_encoder_create_ex(uint8_t quality, uint8_t wavelet_type) {
+    clear_error();
+    if (wavelet_type > 2) { fail(kInvalidBitstream, "unknown wavelet type"); return nullptr; }
+    return new (std::nothrow) FrameEncoder{quality, wavelet_type};
+}
+uint8_t alice_codec_encoder_quality(const FrameEncoder* e) { return e ? e->quality : 0; }
+uint8_t alice_codec_encoder_wavelet(const FrameEncoder* e) { return e ? e->wavelet : 0; }
+uint8_t alice_codec_chunk_wavelet(const EncodedChunk* c) { return c ? c->wavelet : 0; }
+uint64_t alice_codec_chunk_compressed_size(const EncodedChunk* c) { return c ? c->data.size() : 0; }
+
+AliceBatch* alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t frames, uint32_t n_chunks, uint8_t quality,
+                                     uint8_t wavelet_type) {
+    clear_error();
+    if (wavelet_type > 2) { fail(kInvalidBitstream, "unknown wavelet type"); return nullptr; }
+    uint64_t n_pixels = 0;
+    if (checked_pixel_count(width, height, frames, &n_pixels)) return nullptr;
+    if (n_pixels == 0 || n_chunks == 0) { fail(kInvalidDimensions, "empty batch"); return nullptr; }
+    const ChunkDims d = make_dims(width, height, frames);
+    if (d.padded > 0xFFFFFFFFull) { fail(kDimensionOverflow, "padded pixel count exceeds u32"); return nullptr; }
+    if (ensure_device()) return nullptr;
+    AliceBatch* b = new (std::nothrow) AliceBatch();
+    if (!b) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    b->d = d; b->n_chunks = n_chunks; b->quality = quality; b->wavelet = wavelet_type; b->device = tl_device;
+    if (encode_work_alloc(b->enc, d, (int)n_chunks, default_cap(d)) != kOk || b->evs.init() != kOk) { delete b; return nullptr; }
+    return b;
+}
+void alice_codec_batch_destroy(AliceBatch* b) { delete b; }
+
+int alice_codec_batch_encode(AliceBatch* b, const void* d_rgb, void* hip_stream) {
+    clear_error();
+    if (!b || !d_rgb) return fail(kNullArgument, "null argument");
+    TRY(ensure_device());
+    b->enc_stream = (hipStream_t)hip_stream;
+    b->enc_timed = false;
+    return encode_launch((const uint8_t*)d_rgb, b->enc, b->quality, b->wavelet, b->enc_stream, &b->evs);
+}
+int alice_codec_batch_encode_finish(AliceBatch* b, uint64_t* sizes) {
+    clear_error();
+    if (!b) return fail(kNullArgument, "null argument");
+    std::vector<RansResult> res;
+    int rc = encode_collect(b->enc, b->enc_stream, res);
+    if (rc == -1) return fail(kInternal, "rANS output exceeded the batch capacity (1.25 bytes/symbol)");
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&b->stage_ms[i], b->evs.ev[i], b->evs.ev[i + 1]);
+    b->enc_timed = true;
+    if (sizes)
+        for (uint32_t i = 0; i < b->n_chunks; ++i)
+            sizes[i] = (uint64_t)kAlcHeaderBytes + res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
+    return kOk;
+}
+const void* alice_codec_batch_alc_ptr(const AliceBatch* b, uint32_t chunk) {
+    if (!b || chunk >= b->n_chunks) return nullptr;
+    return b->enc.alc.as<uint8_t>() + (size_t)chunk * b->enc.alc_stride;
+}
+uint64_t alice_codec_batch_alc_stride(const AliceBatch* b) { return b ? b->enc.alc_stride : 0; }
+const void* alice_codec_batch_symbols_ptr(const AliceBatch* b) { return b ? b->enc.sym.p : nullptr; }
+uint64_t alice_codec_batch_padded_pixels(const AliceBatch* b) { return b ? b->d.padded : 0; }
+
+int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stride, void* d_rgb_out, void* hip_stream) {
+    clear_error();
+    if (!b || !d_alc || !d_rgb_out) return fail(kNullArgument, "null argument");
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    b->dec_stream = st;
+    b->dec_timed = false;
+    if (!b->dec_ready) { TRY(decode_work_alloc(b->dec, b->d, (int)b->n_chunks)); b->dec_ready = true; }
+    // headers: one strided device-to-host copy, then validation on the host
+    std::vector<uint8_t> hdr((size_t)b->n_chunks * kAlcHeaderBytes);
+    HIP_TRY(hipMemcpy2DAsync(hdr.data(), kAlcHeaderBytes, d_alc, alc_stride, kAlcHeaderBytes, b->n_chunks, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<EncodedChunk> headers(b->n_chunks);
+    std::vector<const uint8_t*> pay(b->n_chunks);
+    for (uint32_t i = 0; i < b->n_chunks; ++i) {
+        uint64_t payload = 0;
+        TRY(parse_alc_header(hdr.data() + (size_t)i * kAlcHeaderBytes, kAlcHeaderBytes, headers[i], &payload));
+        if (headers[i].width != b->d.w || headers[i].height != b->d.h || headers[i].frames != b->d.f)
+            return fail(kInvalidDimensions, "chunk dimensions differ from the batch shape");
+        if ((uint64_t)kAlcHeaderBytes + payload > alc_stride) return fail(kInvalidBitstream, "truncated payload");
+        ChunkDims dd;
+        TRY(validate_for_decode(headers[i], &dd, payload));
+        pay[i] = (const uint8_t*)d_alc + (size_t)i * alc_stride + kAlcHeaderBytes;
+    }
+    return decode_launch(headers, pay, b->dec, (uint8_t*)d_rgb_out, st, &b->evs);
+}
+int alice_codec_batch_decode_finish(AliceBatch* b) {
+    clear_error();
+    if (!b) return fail(kNullArgument, "null argument");
+    TRY(decode_collect(b->dec, b->dec_stream));
+    (void)hipEventElapsedTime(&b->stage_ms[4], b->evs.ev[5], b->evs.ev[6]);
+    (void)hipEventElapsedTime(&b->stage_ms[5], b->evs.ev[6], b->evs.ev[7]);
+    b->dec_timed = true;
+    return kOk;
+}
+int alice_codec_batch_stage_ms(const AliceBatch* b, float out[6]) {
+    if (!b || !out) return kNullArgument;
+    for (int i = 0; i < 6; ++i) out[i] = b->stage_ms[i];
+    return kOk;
+}
+
+// ---- stage level ----
+
+int alice_codec_wavelet2d_forward(uint8_t k, int32_t* img, uint64_t w, uint64_t h) { clear_error(); return wavelet_nd(k, img, w, h, 1, 2, false); }
+int alice_codec_wavelet2d_inverse(uint8_t k, int32_t* img, uint64_t w, uint64_t h) { clear_error(); return wavelet_nd(k, img, w, h, 1, 2, true); }
+int alice_codec_wavelet3d_forward(uint8_t k, int32_t* v, uint64_t w, uint64_t h, uint64_t d) { clear_error(); return wavelet_nd(k, v, w, h, d, 3, false); }
+int alice_codec_wavelet3d_inverse(uint8_t k, int32_t* v, uint64_t w, uint64_t h, uint64_t d) { clear_error(); return wavelet_nd(k, v, w, h, d, 3, true); }
+
+int alice_codec_quantize_buffer(int32_t step, int32_t dead_zone, const int32_t* in, uint64_t n_in, int32_t* out, uint64_t n_out) {
+    clear_error();
+    if ((!in || !out) && n_in) return fail(kNullArgument, "null argument");
+    if (n_out < n_in) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n_in) + ", got " + std::to_string(n_out));
+    if (step == 0) return fail(kInvalidQuantStep, "step 0: the reference divides by zero");
+    if (!n_in) return kOk;
+    return staged<int32_t, int32_t>(in, n_in, out, n_in, [&](const int32_t* a, int32_t* b, hipStream_t st) { launch_quantize(a, b, n_in, step, dead_zone, st); });
+}
+int alice_codec_dequantize_buffer(int32_t step, const int32_t* in, uint64_t n_in, int32_t* out, uint64_t n_out) {
+    clear_error();
+    if ((!in || !out) && n_in) return fail(kNullArgument, "null argument");
+    if (n_out < n_in) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n_in) + ", got " + std::to_string(n_out));
+    if (!n_in) return kOk;
+    return staged<int32_t, int32_t>(in, n_in, out, n_in, [&](const int32_t* a, int32_t* b, hipStream_t st) { launch_dequantize(a, b, n_in, step, st); });
+}
+
+FastQuantizer* alice_codec_fastquant_new(int32_t step) {
+    clear_error();
+    if (step <= 0) { fail(kInvalidQuantStep, "quantization step must be positive, got " + std::to_string(step)); return nullptr; }
+    // src/quant.rs:200-216
+    const uint32_t step_u = (uint32_t)step;
+    const uint32_t extra = 32u - (uint32_t)__builtin_clz(step_u);
+    const uint32_t shift = 32u + extra;
+    const unsigned __int128 power = (unsigned __int128)1 << shift;
+    const uint64_t rec = (uint64_t)((power + step_u - 1) / step_u);
+    return new (std::nothrow) FastQuantizer{rec, shift, step, step};
+}
+FastQuantizer* alice_codec_fastquant_with_dead_zone(int32_t step, int32_t dead_zone) {
+    FastQuantizer* q = alice_codec_fastquant_new(step);
+    if (q) q->dead_zone = dead_zone;
+    return q;
+}
+void alice_codec_fastquant_destroy(FastQuantizer* q) { delete q; }
+int32_t alice_codec_fastquant_step(const FastQuantizer* q) { return q ? q->step : 0; }
+int32_t alice_codec_fastquant_dead_zone(const FastQuantizer* q) { return q ? q->dead_zone : 0; }
+int alice_codec_fastquant_quantize_buffer(const FastQuantizer* q, const int32_t* in, uint64_t n_in, int32_t* out, uint64_t n_out) {
+    clear_error();
+    if (!q || ((!in || !out) && n_in)) return fail(kNullArgument, "null argument");
+    if (n_out < n_in) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n_in) + ", got " + std::to_string(n_out));
+    if (!n_in) return kOk;
+    return staged<int32_t, int32_t>(in, n_in, out, n_in, [&](const int32_t* a, int32_t* b, hipStream_t st) {
+        launch_fast_quantize(a, b, n_in, q->reciprocal, q->shift, q->dead_zone, st);
+    });
+}
+int alice_codec_fastquant_dequantize_buffer(const FastQuantizer* q, const int32_t* in, uint64_t n_in, int32_t* out, uint64_t n_out) {
+    if (!q) { clear_error(); return fail(kNullArgument, "null argument"); }
+    return alice_codec_dequantize_buffer(q->step, in, n_in, out, n_out);
+}
+
+int alice_codec_to_symbols(const int32_t* coeffs, uint64_t n, uint8_t* symbols, uint64_t n_out) {
+    clear_error();
+    if ((!coeffs || !symbols) && n) return fail(kNullArgument, "null argument");
+    if (n_out < n) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n) + ", got " + std::to_string(n_out));
+    if (!n) return kOk;
+    return staged<int32_t, uint8_t>(coeffs, n, symbols, n, [&](const int32_t* a, uint8_t* b, hipStream_t st) { launch_to_symbols(a, b, n, st); });
+}
+int alice_codec_from_symbols(const uint8_t* symbols, uint64_t n, int32_t* coeffs, uint64_t n_out) {
+    clear_error();
+    if ((!coeffs || !symbols) && n) return fail(kNullArgument, "null argument");
+    if (n_out < n) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n) + ", got " + std::to_string(n_out));
+    if (!n) return kOk;
+    return staged<uint8_t, int32_t>(symbols, n, coeffs, n, [&](const uint8_t* a, int32_t* b, hipStream_t st) { launch_from_symbols(a, b, n, st); });
+}
+int alice_codec_build_histogram(const uint8_t* symbols, uint64_t n, uint32_t hist[256]) {
+    clear_error();
+    if (!hist || (!symbols && n)) return fail(kNullArgument, "null argument");
+    return staged<uint8_t, uint32_t>(symbols, n, hist, 256, [&](const uint8_t* a, uint32_t* b, hipStream_t st) {
+        (void)hipMemsetAsync(b, 0, 256 * sizeof(uint32_t), st);
+        launch_histogram(a, n, b, st);
+    });
+}
+
+int alice_codec_freq_table_from_histogram(const uint32_t hist[256], uint16_t cum_freq[256], uint16_t freq[256]) {
+    clear_error();
+    if (!hist || !cum_freq || !freq) return fail(kNullArgument, "null argument");
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf h, t;
+    TRY(h.alloc(256 * 4));
+    TRY(t.alloc(sizeof(RansTable)));
+    HIP_TRY(hipMemcpyAsync(h.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
+    launch_rans_table(h.as<uint32_t>(), t.as<RansTable>(), 1, st);
+    std::vector<RansTable> host(1);
+    HIP_TRY(hipMemcpyAsync(host.data(), t.p, sizeof(RansTable), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < 256; ++i) { cum_freq[i] = (uint16_t)host[0].enc[i].cum; freq[i] = (uint16_t)host[0].enc[i].freq; }
+    return kOk;
+}
+
+uint8_t* alice_codec_rans_encode(const uint8_t* symbols, uint64_t n, const uint16_t cum_freq[256], const uint16_t freq[256],
+                                 uint64_t* out_len) {
+    clear_error();
+    if ((!symbols && n) || !cum_freq || !freq || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
+    hipStream_t st;
+    if (get_stream(&st)) return nullptr;
+    const uint64_t cap = round_up(2 * n + 4 + 64, 256);
+    DevBuf ds, dc, df, dt, dout, dres;
+    if (ds.alloc(n) || dc.alloc(512) || df.alloc(512) || dt.alloc(sizeof(RansTable)) || dout.alloc(cap) || dres.alloc(sizeof(RansResult))) return nullptr;
+    RansResult res{};
+    auto ok = [&](hipError_t e) { if (e != hipSuccess) { fail(kDeviceError, hipGetErrorString(e)); return false; } return true; };
+    if (n && !ok(hipMemcpyAsync(ds.p, symbols, n, hipMemcpyHostToDevice, st))) return nullptr;
+    if (!ok(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st)) || !ok(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st))) return nullptr;
+    launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
+    launch_rans_encode(ds.as<uint8_t>(), n, n, dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), 1, st);
+    if (!ok(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) return nullptr;
+    if (res.flags & kTableDiverges) { fail(kReferenceDiverges, "symbol with table frequency 0 encoded"); return nullptr; }
+    if (res.flags & (kRansOverflow | kRansInternal)) { fail(kInternal, "rANS encode failed"); return nullptr; }
+    uint8_t* p = (uint8_t*)malloc(res.len ? res.len : 1);
+    if (!p) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    if (!ok(hipMemcpyAsync(p, dout.as<uint8_t>() + (cap - res.len), res.len, hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) { free(p); return nullptr; }
+    *out_len = res.len;
+    return p;
+}
+
+int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t cum_freq[256], const uint16_t freq[256],
+                            uint64_t n, uint8_t* symbols) {
+    clear_error();
+    if ((!bytes && len) || !cum_freq || !freq || (!symbols && n)) return fail(kNullArgument, "null argument");
+    if (!n) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf din, dc, df, dt, dout, ddesc, dres;
+    TRY(din.alloc(len + 16)); TRY(dc.alloc(512)); TRY(df.alloc(512)); TRY(dt.alloc(sizeof(RansTable)));
+    TRY(dout.alloc(n)); TRY(ddesc.alloc(sizeof(RansDecodeDesc))); TRY(dres.alloc(sizeof(RansResult)));
+    if (len) HIP_TRY(hipMemcpyAsync(din.p, bytes, len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
+    RansDecodeDesc desc{din.as<uint8_t>(), len, dout.as<uint8_t>(), n, dt.as<RansTable>()};
+    HIP_TRY(hipMemcpyAsync(ddesc.p, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
+    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 1, st);
+    RansResult res{};
+    HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(symbols, dout.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (res.flags & kRansInternal) return fail(kInternal, "decode table outside the packed range (freq > 4096 with live slots)");
+    return kOk;
+}
+
+int alice_codec_rgb_to_ycocg_r(const uint8_t* rgb, uint64_t rgb_len, int16_t* y, int16_t* co, int16_t* cg, uint64_t n_out) {
+    clear_error();
+    if (rgb_len % 3 != 0) return fail(kInvalidBufferSize, "rgb length is not a multiple of 3");  // src/color.rs:205-210
+    const uint64_t n = rgb_len / 3;
+    if (n_out < n) return fail(kInvalidBufferSize, "output planes too small");                   // :212-218
+    if (!n) return kOk;
+    if (!rgb || !y || !co || !cg) return fail(kNullArgument, "null argument");
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf a, b;
+    TRY(a.alloc(rgb_len)); TRY(b.alloc(3 * n * 2));
+    HIP_TRY(hipMemcpyAsync(a.p, rgb, rgb_len, hipMemcpyHostToDevice, st));
+    int16_t* p = b.as<int16_t>();
+    launch_rgb_to_ycocg(a.as<uint8_t>(), n, p, p + n, p + 2 * n, st);
+    HIP_TRY(hipMemcpyAsync(y, p, n * 2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(co, p + n, n * 2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cg, p + 2 * n, n * 2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+int alice_codec_ycocg_r_to_rgb(const int16_t* y, const int16_t* co, const int16_t* cg, uint64_t n, uint8_t* rgb, uint64_t rgb_len) {
+    clear_error();
+    if (rgb_len < n * 3) return fail(kInvalidBufferSize, "rgb buffer too small");  // src/color.rs:258-263
+    if (!n) return kOk;
+    if (!rgb || !y || !co || !cg) return fail(kNullArgument, "null argument");
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf a, b;
+    TRY(a.alloc(3 * n * 2)); TRY(b.alloc(n * 3));
+    int16_t* p = a.as<int16_t>();
+    HIP_TRY(hipMemcpyAsync(p, y, n * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p + n, co, n * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p + 2 * n, cg, n * 2, hipMemcpyHostToDevice, st));
+    launch_ycocg_to_rgb(p, p + n, p + 2 * n, n, b.as<uint8_t>(), st);
+    HIP_TRY(hipMemcpyAsync(rgb, b.p, n * 3, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+}  // extern "C"

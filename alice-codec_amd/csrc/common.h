@@ -1,0 +1,106 @@
+// Shared definitions for the MI355X (gfx950) ALICE-Codec path.
+// Host + device.  No CUDA compatibility layer: HIP for CDNA4 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace alice {
+
+// CodecError, reference src/error.rs:12-23 (+ library-side conditions)
+enum ErrorCode : int {
+    kOk = 0,
+    kInvalidBufferSize = 1,
+    kInvalidDimensions = 2,
+    kDimensionOverflow = 3,
+    kInvalidBitstream = 4,
+    kInvalidQuantStep = 5,
+    // Reference would spin forever / divide by zero (src/rans.rs:275-283): a symbol
+    // whose table frequency wrapped to 0 is present in the data.
+    kReferenceDiverges = 6,
+    kOutOfMemory = 7,
+    kDeviceError = 8,     // HIP runtime failure / no gfx950 device
+    kNullArgument = 9,
+    kInternal = 10,
+};
+
+// WaveletType, reference src/pipeline.rs:34-41
+enum WaveletKind : int { kCdf53 = 0, kCdf97 = 1, kHaar = 2 };
+
+// Lifting coefficient lists, reference src/wavelet.rs:66-127 (scale 2^12).  Every
+// filter alternates predict, update, (predict, update).
+struct LiftSteps {
+    int n;         // 2 or 4
+    int coeff[4];
+};
+
+inline LiftSteps lift_steps(int kind) {
+    LiftSteps s{};
+    switch (kind) {
+    case kCdf97: s.n = 4; s.coeff[0] = -6497; s.coeff[1] = -217; s.coeff[2] = 3616; s.coeff[3] = 1817; break;
+    case kHaar: s.n = 2; s.coeff[0] = -4096; s.coeff[1] = 2048; break;
+    default: s.n = 2; s.coeff[0] = -4096; s.coeff[1] = 1024; break;
+    }
+    return s;
+}
+
+// .alc layout constants, reference src/pipeline.rs:137,148
+constexpr uint32_t kFixedHeaderBytes = 18;
+constexpr uint32_t kChannelHeaderBytes = 1040;
+constexpr uint32_t kAlcHeaderBytes = kFixedHeaderBytes + 3 * kChannelHeaderBytes;  // 3138
+
+constexpr uint32_t kProbBits = 12;
+constexpr uint32_t kProbScale = 1u << kProbBits;
+constexpr uint32_t kRansL = 1u << 23;
+
+// Per-symbol encoder parameters consumed by the rANS encode kernels.
+// Built on the device by rans_table_kernel from the channel histogram.
+struct RansEncEntry {
+    uint32_t xmax;    // freq << 19 (saturated to 2^32-1)
+    uint32_t xmax8;   // freq << 27 (saturated)
+    uint32_t rcp;     // magic reciprocal: floor(y / freq) = umulhi(y, rcp) >> rsh  (y < xmax)
+    uint32_t rsh;
+    int32_t g;        // 4096 - freq            (x' = y + q*g + cbias)
+    uint32_t cbias;   // cum_freq (+4095 when freq == 1, see rans_table_kernel)
+    uint32_t freq;    // as stored in the reference table (u16)
+    uint32_t cum;     // as stored in the reference table (u16)
+};
+static_assert(sizeof(RansEncEntry) == 32, "RansEncEntry must be 32 bytes");
+
+// flags produced by rans_table_kernel
+constexpr uint32_t kTableNeedsGeneric = 1u;   // a symbol present in the data has freq > 4096
+constexpr uint32_t kTableDiverges = 2u;       // a symbol present in the data has freq == 0
+
+struct RansTable {
+    RansEncEntry enc[256];
+    uint32_t flags;
+    uint32_t pad[7];
+};
+
+struct ChunkDims {
+    uint32_t w, h, f;     // as given
+    uint32_t pw, ph, pf;  // padded to even (f == 1 -> 2), reference src/pipeline.rs:437-439
+    uint64_t n_pixels;    // w*h*f
+    uint64_t padded;      // pw*ph*pf
+};
+
+inline ChunkDims make_dims(uint32_t w, uint32_t h, uint32_t f) {
+    ChunkDims d{};
+    d.w = w; d.h = h; d.f = f;
+    d.pw = w + (w & 1u);
+    d.ph = h + (h & 1u);
+    d.pf = (f == 1u) ? 2u : f + (f & 1u);
+    d.n_pixels = (uint64_t)w * h * f;
+    d.padded = (uint64_t)d.pw * d.ph * d.pf;
+    return d;
+}
+
+// reference src/pipeline.rs:456-457
+inline int32_t quality_to_step(uint8_t quality) {
+    int32_t q = quality > 100 ? 100 : quality;
+    int32_t step = 64 - (q * 63) / 100;
+    return step < 1 ? 1 : step;
+}
+
+}  // namespace alice

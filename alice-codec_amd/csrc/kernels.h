@@ -1,0 +1,71 @@
+// Kernel launch interface (host side) for the gfx950 ALICE-Codec path.
+#pragma once
+
+#include "common.h"
+
+namespace alice {
+
+constexpr uint32_t kRansOverflow = 4u;   // output region too small (host retries with 2N+4)
+constexpr uint32_t kRansInternal = 8u;   // invariant violated (never expected)
+
+struct RansResult {
+    unsigned long long len;   // encode: stream bytes; decode: stream bytes consumed
+    uint32_t flags;
+    uint32_t final_state;
+};
+
+struct RansDecodeDesc {
+    const uint8_t* in;        // channel stream
+    unsigned long long in_len;
+    uint8_t* out;             // n symbols
+    unsigned long long n;
+    const RansTable* table;   // built by rans_table_kernel from the stored channel histogram
+};
+
+// ---- rans.hip ----
+void launch_rans_table(const uint32_t* d_hist, RansTable* d_tables, int n_chains, hipStream_t st);
+void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq, RansTable* d_table,
+                                   hipStream_t st);
+// chain c reads sym + c*sym_stride (n symbols) and writes its stream back-to-front into
+// [out + c*cap, out + (c+1)*cap); the stream is the last results[c].len bytes of that region.
+void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
+                        uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st);
+void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
+
+// ---- transform.hip (pipeline-specialised: RGB <-> u8 symbols) ----
+// mid: int32 [3][pf][ph][pw] scratch for one chunk.  hist: uint32 [3][256], zeroed by the caller.
+// Returns false when the shape needs the generic path (pf > 64).
+bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
+                              int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st);
+// steps/dead zones per channel come from the chunk header.  exact = 64-bit lifting products.
+bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
+                              bool exact, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st);
+
+// ---- generic.hip (stage-level API on arbitrary i32 data; exact reference arithmetic) ----
+// 1-D transform of n_lines lines: element k of line (a, b) is at data[a*stride_a + b*stride_b + k*stride_k],
+// a in [0, n_a), b in [0, n_b).  tmp: same size as data.
+void launch_wavelet_axis(int32_t* d_data, int32_t* d_tmp, uint64_t n, uint64_t stride_k, uint64_t n_a,
+                         uint64_t stride_a, uint64_t n_b, uint64_t stride_b, int wavelet, bool inverse,
+                         hipStream_t st);
+void launch_rgb_to_ycocg(const uint8_t* d_rgb, uint64_t n_pixels, int16_t* y, int16_t* co, int16_t* cg, hipStream_t st);
+void launch_ycocg_to_rgb(const int16_t* y, const int16_t* co, const int16_t* cg, uint64_t n_pixels, uint8_t* d_rgb, hipStream_t st);
+void launch_pad_channel(const int16_t* ch, const ChunkDims& d, int32_t* out, hipStream_t st);
+void launch_strip_channel(const int32_t* in, const ChunkDims& d, int16_t* ch, hipStream_t st);
+void launch_quantize(const int32_t* in, int32_t* out, uint64_t n, int32_t step, int32_t dead_zone, hipStream_t st);
+void launch_fast_quantize(const int32_t* in, int32_t* out, uint64_t n, uint64_t reciprocal, uint32_t shift,
+                          int32_t dead_zone, hipStream_t st);
+void launch_dequantize(const int32_t* in, int32_t* out, uint64_t n, int32_t step, hipStream_t st);
+void launch_to_symbols(const int32_t* in, uint8_t* out, uint64_t n, hipStream_t st);
+void launch_from_symbols(const uint8_t* in, int32_t* out, uint64_t n, hipStream_t st);
+void launch_histogram(const uint8_t* sym, uint64_t n, uint32_t* hist /*zeroed*/, hipStream_t st);
+void launch_sq_diff_sum(const uint8_t* a, const uint8_t* b, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st);
+// copies the three streams (each at the tail of its cap-sized region) behind a 3138-byte
+// header slot: d_alc[chunk*alc_stride + 3138 ...]; writes per-chunk total sizes.
+void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, const uint8_t* d_streams, uint64_t cap,
+                            const RansResult* d_results, int n_chunks, hipStream_t st);
+// fills the 3138-byte headers on the device (magic, dims, per-channel fields, histograms)
+void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& d, int wavelet, int32_t step,
+                          const uint32_t* d_hist, const RansResult* d_results, unsigned long long* d_sizes,
+                          int n_chunks, hipStream_t st);
+
+}  // namespace alice

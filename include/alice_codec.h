@@ -1,0 +1,171 @@
+/*
+ * alice_codec.h -- C ABI of libalice_codec.so, the MI355X (gfx950) encode/decode path.
+ *
+ * PART 1 is the drop-in boundary: the 20 functions the reference `cdylib` exports from
+ * src/ffi.rs (C statement of the ABI: bindings/ue5/AliceCodec.h:14-68 in the reference),
+ * with the same names, signatures, ownership and failure conventions (NULL / -1.0 / 0,
+ * `*out_len` written only on success).  Every call runs on the GPU; there is no CPU
+ * fallback -- without a usable HIP device the calls fail (NULL) and
+ * alice_codec_last_error() reports ALICE_ERR_DEVICE.
+ *
+ * PART 2 are extension entry points the reference ABI cannot express: wavelet selection
+ * (the reference FFI can only create CDF 5/3 encoders, src/ffi.rs:92-94), 64-bit lengths
+ * (src/ffi.rs:119 carries u32), device-resident batches of chunks (many rANS chains in
+ * flight is the only parallelism the single-stream format offers), and stage-level calls
+ * for the Rust API surface named by the task (Wavelet2D/3D, Quantizer/FastQuantizer,
+ * to_symbols/from_symbols/build_histogram, FrequencyTable, RansEncoder/RansDecoder, colour).
+ *
+ * Handles are opaque and immutable after creation; encode/decode may be called from many
+ * threads on the same handle (reference: Send + Sync, src/pipeline.rs:635-644).
+ */
+#ifndef ALICE_CODEC_H
+#define ALICE_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Wavelet1D Wavelet1D;
+typedef struct FrameEncoder FrameEncoder;
+typedef struct EncodedChunk EncodedChunk;
+
+/* ===================== PART 1: reference ABI (src/ffi.rs) ===================== */
+
+Wavelet1D *alice_codec_wavelet1d_haar(void);                 /* src/ffi.rs:16  */
+Wavelet1D *alice_codec_wavelet1d_cdf53(void);                /* src/ffi.rs:22  */
+Wavelet1D *alice_codec_wavelet1d_cdf97(void);                /* src/ffi.rs:28  */
+void alice_codec_wavelet1d_destroy(Wavelet1D *ptr);          /* src/ffi.rs:38  null-ok */
+/* no-op if wavelet/data is NULL or len < 2 */
+void alice_codec_wavelet1d_forward(const Wavelet1D *wavelet, int32_t *data, uint32_t len); /* src/ffi.rs:52 */
+void alice_codec_wavelet1d_inverse(const Wavelet1D *wavelet, int32_t *data, uint32_t len); /* src/ffi.rs:73 */
+
+FrameEncoder *alice_codec_encoder_create(uint8_t quality);   /* src/ffi.rs:92  always CDF 5/3 */
+void alice_codec_encoder_destroy(FrameEncoder *ptr);         /* src/ffi.rs:102 null-ok */
+/* NULL on any error or NULL argument */
+EncodedChunk *alice_codec_encode(const FrameEncoder *encoder, const uint8_t *rgb, uint32_t rgb_len,
+                                 uint32_t width, uint32_t height, uint32_t frames); /* src/ffi.rs:116 */
+/* NULL on error; caller frees with alice_codec_data_free(ptr, *out_len) */
+uint8_t *alice_codec_decode(const EncodedChunk *chunk, uint32_t *out_len);          /* src/ffi.rs:145 */
+
+void alice_codec_chunk_destroy(EncodedChunk *ptr);                                  /* src/ffi.rs:171 */
+uint8_t *alice_codec_chunk_to_bytes(const EncodedChunk *chunk, uint32_t *out_len);  /* src/ffi.rs:185 */
+EncodedChunk *alice_codec_chunk_from_bytes(const uint8_t *data, uint32_t len);      /* src/ffi.rs:207 */
+uint32_t alice_codec_chunk_width(const EncodedChunk *chunk);                        /* src/ffi.rs:226 */
+uint32_t alice_codec_chunk_height(const EncodedChunk *chunk);                       /* src/ffi.rs:240 */
+uint32_t alice_codec_chunk_frames(const EncodedChunk *chunk);                       /* src/ffi.rs:254 */
+
+/* -1.0 on NULL; +inf when identical or empty */
+double alice_codec_psnr(const uint8_t *a, const uint8_t *b, uint32_t len);          /* src/ffi.rs:270 */
+
+void alice_codec_data_free(uint8_t *ptr, uint32_t len);                             /* src/ffi.rs:288 */
+void alice_codec_string_free(char *s);                                              /* src/ffi.rs:302 */
+char *alice_codec_version(void);                                                    /* src/ffi.rs:311 */
+
+/* ===================== PART 2: extensions ===================== */
+
+/* CodecError (src/error.rs:12-23) as integers, plus library-side conditions */
+enum {
+    ALICE_OK = 0,
+    ALICE_ERR_INVALID_BUFFER_SIZE = 1,
+    ALICE_ERR_INVALID_DIMENSIONS = 2,
+    ALICE_ERR_DIMENSION_OVERFLOW = 3,
+    ALICE_ERR_INVALID_BITSTREAM = 4,
+    ALICE_ERR_INVALID_QUANT_STEP = 5,
+    ALICE_ERR_REFERENCE_DIVERGES = 6, /* the reference would hang/divide by zero (src/rans.rs:275-283) */
+    ALICE_ERR_OUT_OF_MEMORY = 7,
+    ALICE_ERR_DEVICE = 8,
+    ALICE_ERR_NULL_ARGUMENT = 9,
+    ALICE_ERR_INTERNAL = 10
+};
+/* WaveletType (src/pipeline.rs:34-41) */
+enum { ALICE_WAVELET_CDF53 = 0, ALICE_WAVELET_CDF97 = 1, ALICE_WAVELET_HAAR = 2 };
+
+int alice_codec_last_error(void);                 /* code of the last failing call on this thread */
+const char *alice_codec_last_error_message(void); /* thread-local, valid until the next call */
+int alice_codec_device_count(void);
+int alice_codec_set_device(int device);           /* device used by this thread's later calls */
+void alice_codec_trim(void);                      /* release cached device memory */
+
+/* FrameEncoder::with_wavelet (src/pipeline.rs:356) */
+FrameEncoder *alice_codec_encoder_create_ex(uint8_t quality, uint8_t wavelet_type);
+uint8_t alice_codec_encoder_quality(const FrameEncoder *encoder);
+uint8_t alice_codec_encoder_wavelet(const FrameEncoder *encoder);
+/* EncodedChunk public fields / compressed_size (src/pipeline.rs:172-192) */
+uint8_t alice_codec_chunk_wavelet(const EncodedChunk *chunk);
+uint64_t alice_codec_chunk_compressed_size(const EncodedChunk *chunk);
+
+/* 64-bit length variants of #9, #10, #12, #13, #18 */
+EncodedChunk *alice_codec_encode64(const FrameEncoder *encoder, const uint8_t *rgb, uint64_t rgb_len,
+                                   uint32_t width, uint32_t height, uint32_t frames);
+uint8_t *alice_codec_decode64(const EncodedChunk *chunk, uint64_t *out_len);
+uint8_t *alice_codec_chunk_to_bytes64(const EncodedChunk *chunk, uint64_t *out_len);
+EncodedChunk *alice_codec_chunk_from_bytes64(const uint8_t *data, uint64_t len);
+void alice_codec_data_free64(uint8_t *ptr, uint64_t len);
+
+/* ---- device-resident batches: n_chunks equal-shaped chunks, inputs and outputs in HBM ---- */
+typedef struct AliceBatch AliceBatch;
+AliceBatch *alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t frames, uint32_t n_chunks,
+                                     uint8_t quality, uint8_t wavelet_type);
+void alice_codec_batch_destroy(AliceBatch *batch);
+/* d_rgb: device pointer to n_chunks * width*height*frames*3 bytes.  hip_stream: hipStream_t (NULL = default).
+ * Asynchronous; the .alc buffers stay on the device. Returns an ALICE_* code. */
+int alice_codec_batch_encode(AliceBatch *batch, const void *d_rgb, void *hip_stream);
+/* waits for the encode, checks per-chain flags, writes the .alc size of each chunk */
+int alice_codec_batch_encode_finish(AliceBatch *batch, uint64_t *sizes /* n_chunks */);
+const void *alice_codec_batch_alc_ptr(const AliceBatch *batch, uint32_t chunk); /* device pointer */
+uint64_t alice_codec_batch_alc_stride(const AliceBatch *batch);
+/* d_alc: device pointer, chunk i at d_alc + i*alc_stride (whole .alc, header first).
+ * d_rgb_out: device pointer to n_chunks * width*height*frames*3 bytes. Synchronises once to read headers. */
+int alice_codec_batch_decode(AliceBatch *batch, const void *d_alc, uint64_t alc_stride, void *d_rgb_out,
+                             void *hip_stream);
+int alice_codec_batch_decode_finish(AliceBatch *batch);
+/* per-stage device times of the last encode+finish / decode+finish, measured with HIP events on the
+ * batch's stream: [0] forward transform, [1] table, [2] rANS encode, [3] assemble,
+ * [4] rANS decode, [5] inverse transform.  Milliseconds. */
+int alice_codec_batch_stage_ms(const AliceBatch *batch, float out[6]);
+/* device pointer to the batch's u8 symbols (3 * padded per chunk, channel-major) -- for parity tests */
+const void *alice_codec_batch_symbols_ptr(const AliceBatch *batch);
+uint64_t alice_codec_batch_padded_pixels(const AliceBatch *batch);
+
+/* ---- stage level (host pointers; data is staged through the GPU) ---- */
+/* Wavelet2D / Wavelet3D forward/inverse (src/wavelet.rs:292-340, 392-484), in place */
+int alice_codec_wavelet2d_forward(uint8_t wavelet_type, int32_t *image, uint64_t width, uint64_t height);
+int alice_codec_wavelet2d_inverse(uint8_t wavelet_type, int32_t *image, uint64_t width, uint64_t height);
+int alice_codec_wavelet3d_forward(uint8_t wavelet_type, int32_t *volume, uint64_t width, uint64_t height, uint64_t depth);
+int alice_codec_wavelet3d_inverse(uint8_t wavelet_type, int32_t *volume, uint64_t width, uint64_t height, uint64_t depth);
+/* Quantizer::{quantize_buffer,dequantize_buffer} (src/quant.rs:117-146); error if n_out < n_in */
+int alice_codec_quantize_buffer(int32_t step, int32_t dead_zone, const int32_t *in, uint64_t n_in, int32_t *out, uint64_t n_out);
+int alice_codec_dequantize_buffer(int32_t step, const int32_t *in, uint64_t n_in, int32_t *out, uint64_t n_out);
+/* FastQuantizer (src/quant.rs:171-359) */
+typedef struct FastQuantizer FastQuantizer;
+FastQuantizer *alice_codec_fastquant_new(int32_t step);                              /* NULL if step <= 0 */
+FastQuantizer *alice_codec_fastquant_with_dead_zone(int32_t step, int32_t dead_zone);
+void alice_codec_fastquant_destroy(FastQuantizer *q);
+int32_t alice_codec_fastquant_step(const FastQuantizer *q);
+int32_t alice_codec_fastquant_dead_zone(const FastQuantizer *q);
+int alice_codec_fastquant_quantize_buffer(const FastQuantizer *q, const int32_t *in, uint64_t n_in, int32_t *out, uint64_t n_out);
+int alice_codec_fastquant_dequantize_buffer(const FastQuantizer *q, const int32_t *in, uint64_t n_in, int32_t *out, uint64_t n_out);
+/* to_symbols / from_symbols / build_histogram (src/quant.rs:547-600) */
+int alice_codec_to_symbols(const int32_t *coeffs, uint64_t n, uint8_t *symbols, uint64_t n_out);
+int alice_codec_from_symbols(const uint8_t *symbols, uint64_t n, int32_t *coeffs, uint64_t n_out);
+int alice_codec_build_histogram(const uint8_t *symbols, uint64_t n, uint32_t hist[256]);
+/* FrequencyTable::from_histogram over 256 bins (src/rans.rs:102-150): writes cum_freq[256], freq[256] */
+int alice_codec_freq_table_from_histogram(const uint32_t hist[256], uint16_t cum_freq[256], uint16_t freq[256]);
+/* RansEncoder::new().encode_symbols(symbols, table).finish() (src/rans.rs:288-308); table given as arrays.
+ * Returns a buffer to free with alice_codec_data_free64, NULL on error. */
+uint8_t *alice_codec_rans_encode(const uint8_t *symbols, uint64_t n, const uint16_t cum_freq[256],
+                                 const uint16_t freq[256], uint64_t *out_len);
+/* RansDecoder::new(bytes).decode_n(n, table) (src/rans.rs:330-381); cum_to_sym is rebuilt from the arrays */
+int alice_codec_rans_decode(const uint8_t *bytes, uint64_t len, const uint16_t cum_freq[256],
+                            const uint16_t freq[256], uint64_t n, uint8_t *symbols);
+/* rgb_bytes_to_ycocg_r / ycocg_r_to_rgb_bytes (src/color.rs:199-276) */
+int alice_codec_rgb_to_ycocg_r(const uint8_t *rgb, uint64_t rgb_len, int16_t *y, int16_t *co, int16_t *cg, uint64_t n_out);
+int alice_codec_ycocg_r_to_rgb(const int16_t *y, const int16_t *co, const int16_t *cg, uint64_t n, uint8_t *rgb, uint64_t rgb_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALICE_CODEC_H */
