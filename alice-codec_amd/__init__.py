@@ -56,6 +56,31 @@ _u64p = C.POINTER(C.c_uint64)
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so.7 / libhsa-runtime64 next to libtorch; libalice_codec.so is linked against
+    the same SONAME.  If the system copy were loaded first and torch's afterwards, two HSA
+    runtimes would fight over the device ("No HIP GPUs are available").  When torch is
+    installed, load its copy first so both bind to it, whatever the import order.  Set
+    ALICE_CODEC_HIP_RUNTIME=system to skip this (pure C/C++ hosts never need it)."""
+    if os.environ.get("ALICE_CODEC_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    import sys
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if "torch" not in sys.modules and os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library() -> C.CDLL:
     """dlopen libalice_codec.so (built in-tree by ``__graft_entry__.build()``)."""
     global _lib
@@ -65,6 +90,7 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library is the product path and has no fallback. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     sig = {

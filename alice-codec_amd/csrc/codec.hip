@@ -659,13 +659,13 @@ Wavelet1D* alice_codec_wavelet1d_cdf97(void) { return new (std::nothrow) Wavelet
 void alice_codec_wavelet1d_destroy(Wavelet1D* ptr) { delete ptr; }
 
 void alice_codec_wavelet1d_forward(const Wavelet1D* w, int32_t* data, uint32_t len) {
-    if (!w || !data || len < 2) return;
     clear_error();
+    if (!w || !data || len < 2) return;
     (void)wavelet_nd(w->kind, data, len, 1, 1, 1, false);
 }
 void alice_codec_wavelet1d_inverse(const Wavelet1D* w, int32_t* data, uint32_t len) {
-    if (!w || !data || len < 2) return;
     clear_error();
+    if (!w || !data || len < 2) return;
     (void)wavelet_nd(w->kind, data, len, 1, 1, 1, true);
 }
 
