@@ -136,6 +136,7 @@ def load_library() -> C.CDLL:
         "alice_codec_batch_encode_finish": (C.c_int, [vp, _u64p]),
         "alice_codec_batch_alc_ptr": (vp, [vp, C.c_uint32]),
         "alice_codec_batch_alc_stride": (C.c_uint64, [vp]),
+        "alice_codec_batch_pack_alc": (C.c_int, [vp, _u64p, vp, C.c_uint64, vp]),
         "alice_codec_batch_decode": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
         "alice_codec_batch_decode_finish": (C.c_int, [vp]),
         "alice_codec_batch_stage_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
@@ -656,6 +657,10 @@ class Batch:
     @property
     def alc_stride(self) -> int:
         return load_library().alice_codec_batch_alc_stride(self._h)
+
+    def pack_alc(self, sizes: np.ndarray, d_dst_ptr: int, dst_capacity: int, stream: int = 0) -> None:
+        sizes = np.ascontiguousarray(sizes, np.uint64)
+        _check(load_library().alice_codec_batch_pack_alc(self._h, _p(sizes, _u64p), d_dst_ptr, dst_capacity, stream))
 
     def decode(self, d_alc_ptr: int, alc_stride: int, d_rgb_out_ptr: int, stream: int = 0) -> None:
         _check(load_library().alice_codec_batch_decode(self._h, d_alc_ptr, alc_stride, d_rgb_out_ptr, stream))

@@ -479,6 +479,10 @@ int decode_collect(DecodeWork& w, hipStream_t st) {
     HIP_TRY(hipStreamSynchronize(st));
     for (auto& r : res)
         if (r.flags & kRansInternal) return fail(kInternal, "rANS decode table invariant violated");
+    if (getenv("ALICE_CODEC_DEBUG"))
+        for (size_t i = 0; i < res.size(); ++i)
+            fprintf(stderr, "[alice] decode chain %zu: consumed %llu bytes, fast tiles %u, slow tiles %u\n", i, res[i].len,
+                    res[i].fast_tiles, res[i].slow_tiles);
     return kOk;
 }
 
@@ -849,6 +853,19 @@ const void* alice_codec_batch_alc_ptr(const AliceBatch* b, uint32_t chunk) {
 uint64_t alice_codec_batch_alc_stride(const AliceBatch* b) { return b ? b->enc.alc_stride : 0; }
 const void* alice_codec_batch_symbols_ptr(const AliceBatch* b) { return b ? b->enc.sym.p : nullptr; }
 uint64_t alice_codec_batch_padded_pixels(const AliceBatch* b) { return b ? b->d.padded : 0; }
+
+int alice_codec_batch_pack_alc(AliceBatch* b, const uint64_t* sizes, void* d_dst, uint64_t dst_capacity, void* hip_stream) {
+    clear_error();
+    if (!b || !sizes || !d_dst) return fail(kNullArgument, "null argument");
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < b->n_chunks; ++i) {
+        if (sizes[i] > b->enc.alc_stride || off + sizes[i] > dst_capacity) return fail(kInvalidBufferSize, "pack buffer too small");
+        HIP_TRY(hipMemcpyAsync((uint8_t*)d_dst + off, b->enc.alc.as<uint8_t>() + (size_t)i * b->enc.alc_stride, sizes[i],
+                               hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+        off += sizes[i];
+    }
+    return kOk;
+}
 
 int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stride, void* d_rgb_out, void* hip_stream) {
     clear_error();

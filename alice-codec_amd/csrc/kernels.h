@@ -12,6 +12,8 @@ struct RansResult {
     unsigned long long len;   // encode: stream bytes; decode: stream bytes consumed
     uint32_t flags;
     uint32_t final_state;
+    uint32_t fast_tiles;      // decode: tiles taken by the scalar fast path / by the exact lane loop
+    uint32_t slow_tiles;
 };
 
 struct RansDecodeDesc {

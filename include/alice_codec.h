@@ -117,6 +117,10 @@ int alice_codec_batch_encode(AliceBatch *batch, const void *d_rgb, void *hip_str
 int alice_codec_batch_encode_finish(AliceBatch *batch, uint64_t *sizes /* n_chunks */);
 const void *alice_codec_batch_alc_ptr(const AliceBatch *batch, uint32_t chunk); /* device pointer */
 uint64_t alice_codec_batch_alc_stride(const AliceBatch *batch);
+/* copies the n_chunks finished .alc buffers back to back into d_dst (device), in chunk order:
+ * the contiguous byte blob a rank contributes to the multi-GPU gather. Asynchronous. */
+int alice_codec_batch_pack_alc(AliceBatch *batch, const uint64_t *sizes, void *d_dst, uint64_t dst_capacity,
+                               void *hip_stream);
 /* d_alc: device pointer, chunk i at d_alc + i*alc_stride (whole .alc, header first).
  * d_rgb_out: device pointer to n_chunks * width*height*frames*3 bytes. Synchronises once to read headers. */
 int alice_codec_batch_decode(AliceBatch *batch, const void *d_alc, uint64_t alc_stride, void *d_rgb_out,
