@@ -1,21 +1,30 @@
 // Pipeline-specialised transform kernels for gfx950: RGB <-> u8 symbols.
 //
 // Forward (FrameEncoder::encode, reference src/pipeline.rs:429-477):
-//   fwd_xy_kernel : RGB -> YCoCg-R (src/color.rs:221-228) -> edge-replicated padding
-//                   (src/pipeline.rs:77-114, done by index clamping) -> row lifting -> column
-//                   lifting per frame (src/wavelet.rs:401-417), all inside one LDS tile with a
-//                   halo of one sample per lifting step; writes [L|H]-deinterleaved planes.
-//   fwd_t_kernel  : temporal lifting with the whole temporal vector of a pixel in registers
-//                   (src/wavelet.rs:421-437), fused Quantizer::quantize (src/quant.rs:89-97),
-//                   to_symbols (src/quant.rs:555-560) and build_histogram (:594-600).
+//   fwd_xy_kernel : per frame and 128x40 tile.  Stage A: a thread owns a 16-pixel row segment
+//                   (+ one halo sample per lifting step on each side): RGB -> YCoCg-R
+//                   (src/color.rs:221-228), edge-replicated padding by index clamping
+//                   (src/pipeline.rs:77-114), row lifting entirely in registers
+//                   (src/wavelet.rs:401-405).  The tile goes through LDS once (the transpose).
+//                   Stage B: a thread owns one column of the tile (+halo rows) in registers, column
+//                   lifting (:408-417), i16 store to the [L|H]-deinterleaved plane.
+//   fwd_t_kernel  : temporal lifting as a stream over frame pairs with a five-value window per
+//                   pixel (src/wavelet.rs:421-437), 4 pixels per thread (8-byte loads, 4-byte stores),
+//                   fused Quantizer::quantize (src/quant.rs:89-97), to_symbols (:555-560) and
+//                   build_histogram (:594-600).  Any frame count.
 // Inverse (FrameDecoder::decode, src/pipeline.rs:588-621) mirrors it:
-//   inv_t_kernel  : from_symbols, dequantize, inverse temporal lifting.
-//   inv_xy_kernel : inverse column then row lifting, `as i16`, ycocg_r_to_rgb_bytes.
+//   inv_t_kernel  : from_symbols, dequantize, inverse temporal lifting (stream over pairs).
+//   inv_xy_kernel : stage A inverse column lifting (registers) -> LDS -> stage B inverse row lifting,
+//                   `as i16`, ycocg_r_to_rgb_bytes.
 //
-// Lifting facts used: inside one lifting step every write depends only on samples of the
-// other parity, so a step is data-parallel; an output depends on inputs within +-n_steps
-// samples; mirroring happens only at the true signal ends (src/wavelet.rs:186-190,206-210).
-// A tile whose halo is recomputed therefore yields the same integers as the global pass.
+// Lifting facts used: inside one lifting step every write depends only on samples of the other
+// parity, so a step is data-parallel; an output depends on inputs within +-n_steps samples;
+// mirroring happens only at the true signal ends (src/wavelet.rs:186-190,206-210).  A tile or
+// segment whose halo is recomputed therefore yields the same integers as the global pass.
+//
+// Intermediates: the forward path stores i16 (from u8 input every value in the transform stays
+// below 2^13 in magnitude, SURVEY.md section 7 hard part 5); the inverse path stores i32 because a
+// desynchronised decoder feeds it arbitrary symbols (i16 when the host proves the bound).
 #include "common.h"
 #include "kernels.h"
 
@@ -35,173 +44,237 @@ __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (
 
 struct Coeffs { int c[4]; };
 
-constexpr int TW = 64;  // tile interior width  (even)
-constexpr int TH = 32;  // tile interior height (even)
-
-// One in-place lifting step over all lines of a deinterleaved LDS tile.
-// AXIS 0: along x (pairs indexed by j in [0, EWh)); AXIS 1: along y.
-// Storage: L[ch][(ly&1)*EHh + ly/2][(lx&1)*EWh + lx/2].
-template <int EW, int EH, bool EXACT, bool PREDICT, int AXIS>
-__device__ __forceinline__ void tile_lift_step(int (*L)[EH][EW], int coeff, int gpair0, int n_axis, int tid) {
-    constexpr int EWh = EW / 2, EHh = EH / 2;
-    if (AXIS == 0) {
-        constexpr int items = 3 * EH * EWh;
-        for (int it = tid; it < items; it += 256) {
-            const int j = it % EWh;
-            const int row = (it / EWh) % EH;
-            const int ch = it / (EWh * EH);
-            const int gi = gpair0 + j;
-            int* E = &L[ch][row][0];
-            int* O = &L[ch][row][EWh];
-            if (PREDICT) {
-                const int jn = (j + 1 < EWh && 2 * gi + 2 < n_axis) ? j + 1 : j;
-                O[j] = wadd(O[j], lift_delta<EXACT>(E[j], E[jn], coeff));
-            } else {
-                const int jl = (j > 0 && gi > 0) ? j - 1 : j;
-                E[j] = wadd(E[j], lift_delta<EXACT>(O[jl], O[j], coeff));
+// ------------------------------------------------------------------------------------------------
+// In-register 1-D lifting of N consecutive samples (v[0] has even global index g0).
+// EDGE: g0 + k may fall outside [0, n); mirrors follow the reference at the true ends, array ends
+// clamp (their garbage stays inside the halo).  INVERSE applies the steps reversed with -coeff.
+// ------------------------------------------------------------------------------------------------
+template <int N, int NS, bool EDGE, bool EXACT, bool INVERSE>
+__device__ __forceinline__ void lift_regs(int (&v)[N], const Coeffs& cf, int g0, int n) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k_step = INVERSE ? (NS - 1 - s) : s;
+        const int c = INVERSE ? -cf.c[k_step] : cf.c[k_step];
+        if ((k_step & 1) == 0) {  // predict: odd += d(even_left, even_right), src/wavelet.rs:184-196
+#pragma unroll
+            for (int k = 1; k < N; k += 2) {
+                int right;
+                if (k + 1 < N) right = (!EDGE || (g0 + k + 1 < n)) ? v[k + 1] : v[k - 1];
+                else right = v[k - 1];
+                v[k] = wadd(v[k], lift_delta<EXACT>(v[k - 1], right, c));
             }
-        }
-    } else {
-        constexpr int items = 3 * EHh * EW;
-        for (int it = tid; it < items; it += 256) {
-            const int col = it % EW;
-            const int i = (it / EW) % EHh;
-            const int ch = it / (EW * EHh);
-            const int gi = gpair0 + i;
-            if (PREDICT) {
-                const int in = (i + 1 < EHh && 2 * gi + 2 < n_axis) ? i + 1 : i;
-                L[ch][EHh + i][col] = wadd(L[ch][EHh + i][col], lift_delta<EXACT>(L[ch][i][col], L[ch][in][col], coeff));
-            } else {
-                const int il = (i > 0 && gi > 0) ? i - 1 : i;
-                L[ch][i][col] = wadd(L[ch][i][col], lift_delta<EXACT>(L[ch][EHh + il][col], L[ch][EHh + i][col], coeff));
+        } else {                  // update: even += d(odd_left, odd_right), src/wavelet.rs:205-216
+#pragma unroll
+            for (int k = 0; k < N; k += 2) {
+                const int rgt = (k + 1 < N) ? v[k + 1] : v[k - 1];
+                int left;
+                if (k >= 1) left = (!EDGE || (g0 + k > 0)) ? v[k - 1] : rgt;
+                else left = rgt;
+                v[k] = wadd(v[k], lift_delta<EXACT>(left, rgt, c));
             }
         }
     }
-    __syncthreads();
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void fwd_xy_kernel(const uint8_t* __restrict__ rgb, int32_t* __restrict__ mid,
-                                                     ChunkDims d, Coeffs cf) {
-    constexpr int H = NS;  // halo per side (even)
-    constexpr int EW = TW + 2 * H, EH = TH + 2 * H, EWh = EW / 2, EHh = EH / 2;
-    __shared__ int L[3][EH][EW];
+// ------------------------------------------------------------------------------------------------
+// K1: forward spatial transform of one frame tile
+// ------------------------------------------------------------------------------------------------
+constexpr int F_TW = 128, F_TH = 40, F_SEG = 16, F_NSEG = 8, F_THREADS = 384;
+
+template <int NS, bool EDGE>
+__global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __restrict__ rgb, int16_t* __restrict__ mid,
+                                                                  ChunkDims d, Coeffs cf, int aligned, int bx0, int by0) {
+    // (bx0, by0): tile origin of the launch region (interior rectangle or one of the border strips)
+    constexpr int H = NS;
+    constexpr int ER = F_TH + 2 * H;
+    constexpr int SE = F_SEG + 8;
+    constexpr int K0 = 4 - H;
+    constexpr int NL = F_SEG + 2 * H;
+    extern __shared__ int lds[];
     const int tid = threadIdx.x;
-    const int gx0 = blockIdx.x * TW, gy0 = blockIdx.y * TH, t = blockIdx.z;
+    const int gx0 = (blockIdx.x + bx0) * F_TW, gy0 = (blockIdx.y + by0) * F_TH, t = blockIdx.z;
     const int pw = d.pw, ph = d.ph;
     const int st = min(t, (int)d.f - 1);
 
-    for (int it = tid; it < EH * EW; it += 256) {
-        const int lx = it % EW, ly = it / EW;
-        const int gx = gx0 - H + lx, gy = gy0 - H + ly;
-        int y = 0, co = 0, cg = 0;
-        if (gx >= 0 && gx < pw && gy >= 0 && gy < ph) {
-            const int sx = min(gx, (int)d.w - 1), sy = min(gy, (int)d.h - 1);
-            const uint8_t* p = rgb + (((size_t)st * d.h + sy) * d.w + sx) * 3;
-            const int r = p[0], g = p[1], b = p[2];
-            co = r - b;
-            const int tt = b + (co >> 1);
-            cg = g - tt;
-            y = tt + (cg >> 1);
+    if (tid < ER * F_NSEG) {
+        const int r = tid >> 3, s = tid & 7;
+        const int gy = gy0 - H + r;
+        if (!EDGE || (gy >= 0 && gy < ph)) {
+            const int sy = EDGE ? min(gy, (int)d.h - 1) : gy;
+            const int gxs = gx0 - 4 + s * F_SEG;
+            const uint8_t* row = rgb + ((size_t)st * d.h + sy) * d.w * 3;
+            int y[SE], co[SE], cg[SE];
+            if (!EDGE && aligned) {
+                const uint32_t* p4 = (const uint32_t*)(row + (ptrdiff_t)gxs * 3);
+                uint32_t wd[18];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) wd[i] = p4[i];
+#pragma unroll
+                for (int k = 0; k < SE; ++k) {
+                    const int b0 = 3 * k;
+                    const int rr = (wd[b0 >> 2] >> (8 * (b0 & 3))) & 0xFF;
+                    const int gg = (wd[(b0 + 1) >> 2] >> (8 * ((b0 + 1) & 3))) & 0xFF;
+                    const int bb = (wd[(b0 + 2) >> 2] >> (8 * ((b0 + 2) & 3))) & 0xFF;
+                    const int c_o = rr - bb;
+                    const int tt = bb + (c_o >> 1);
+                    const int c_g = gg - tt;
+                    y[k] = tt + (c_g >> 1); co[k] = c_o; cg[k] = c_g;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < SE; ++k) {
+                    const int gx = gxs + k;
+                    const int sx = min(max(gx, 0), (int)d.w - 1);
+                    const uint8_t* p = row + (size_t)sx * 3;
+                    const int rr = p[0], gg = p[1], bb = p[2];
+                    const int c_o = rr - bb;
+                    const int tt = bb + (c_o >> 1);
+                    const int c_g = gg - tt;
+                    y[k] = tt + (c_g >> 1); co[k] = c_o; cg[k] = c_g;
+                }
+            }
+            int ly[NL], lco[NL], lcg[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) { ly[k] = y[K0 + k]; lco[k] = co[K0 + k]; lcg[k] = cg[K0 + k]; }
+            const int g0 = gxs + K0;
+            lift_regs<NL, NS, EDGE, false, false>(ly, cf, g0, pw);
+            lift_regs<NL, NS, EDGE, false, false>(lco, cf, g0, pw);
+            lift_regs<NL, NS, EDGE, false, false>(lcg, cf, g0, pw);
+            int* L0 = lds + (0 * ER + r) * F_TW;
+            int* L1 = lds + (1 * ER + r) * F_TW;
+            int* L2 = lds + (2 * ER + r) * F_TW;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                L0[s * 8 + j] = ly[H + 2 * j];       L0[64 + s * 8 + j] = ly[H + 2 * j + 1];
+                L1[s * 8 + j] = lco[H + 2 * j];      L1[64 + s * 8 + j] = lco[H + 2 * j + 1];
+                L2[s * 8 + j] = lcg[H + 2 * j];      L2[64 + s * 8 + j] = lcg[H + 2 * j + 1];
+            }
         }
-        const int rr = (ly & 1) * EHh + (ly >> 1), cc = (lx & 1) * EWh + (lx >> 1);
-        L[0][rr][cc] = y;
-        L[1][rr][cc] = co;
-        L[2][rr][cc] = cg;
     }
     __syncthreads();
-
-    const int gpx0 = (gx0 - H) / 2, gpy0 = (gy0 - H) / 2;  // H even, gx0 even -> exact (also when negative)
-    tile_lift_step<EW, EH, false, true, 0>(L, cf.c[0], gpx0, pw, tid);
-    tile_lift_step<EW, EH, false, false, 0>(L, cf.c[1], gpx0, pw, tid);
-    if (NS == 4) {
-        tile_lift_step<EW, EH, false, true, 0>(L, cf.c[2], gpx0, pw, tid);
-        tile_lift_step<EW, EH, false, false, 0>(L, cf.c[3], gpx0, pw, tid);
-    }
-    tile_lift_step<EW, EH, false, true, 1>(L, cf.c[0], gpy0, ph, tid);
-    tile_lift_step<EW, EH, false, false, 1>(L, cf.c[1], gpy0, ph, tid);
-    if (NS == 4) {
-        tile_lift_step<EW, EH, false, true, 1>(L, cf.c[2], gpy0, ph, tid);
-        tile_lift_step<EW, EH, false, false, 1>(L, cf.c[3], gpy0, ph, tid);
-    }
-
-    // interior -> mid[ch][t][yy][xx], already deinterleaved ([L|H] along x and y)
-    const int hw = pw / 2, hh = ph / 2;
-    for (int it = tid; it < 3 * TH * TW; it += 256) {
-        const int c = it % TW;             // 0..31 even half, 32..63 odd half
-        const int r = (it / TW) % TH;
-        const int ch = it / (TW * TH);
-        const int px = c / (TW / 2), jx = c % (TW / 2);
-        const int py = r / (TH / 2), jy = r % (TH / 2);
-        const int gxp = gx0 / 2 + jx, gyp = gy0 / 2 + jy;  // global pair indices
-        if (gxp < hw && gyp < hh) {
-            const int v = L[ch][py * EHh + H / 2 + jy][px * EWh + H / 2 + jx];
-            mid[(((size_t)ch * d.pf + t) * ph + (py * hh + gyp)) * pw + (px * hw + gxp)] = v;
+    {
+        const int xq = tid & 127, ch = tid >> 7;
+        const int par = xq >> 6, j = xq & 63;
+        const int gxp = gx0 / 2 + j;
+        const int hw = pw / 2, hh = ph / 2;
+        if (!EDGE || gxp < hw) {
+            int v[ER];
+            const int* L = lds + (ch * ER) * F_TW + xq;
+#pragma unroll
+            for (int r = 0; r < ER; ++r) v[r] = L[r * F_TW];
+            lift_regs<ER, NS, EDGE, false, false>(v, cf, gy0 - H, ph);
+            int16_t* out = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
+#pragma unroll
+            for (int k = 0; k < F_TH; ++k) {
+                const int gy = gy0 + k;
+                if (!EDGE || gy < ph) {
+                    const int yy = (gy & 1) * hh + (gy >> 1);
+                    out[(size_t)yy * pw] = (int16_t)v[H + k];
+                }
+            }
         }
     }
 }
 
-// Temporal lifting + quantise + symbol + histogram.  One thread per (channel, y, x).
-template <int NS, int MAXF>
-__global__ __launch_bounds__(256) void fwd_t_kernel(const int32_t* __restrict__ mid, uint8_t* __restrict__ sym,
-                                                    uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf,
-                                                    int step, uint32_t magic) {
+
+// ------------------------------------------------------------------------------------------------
+// K2: forward temporal lifting (stream over frame pairs) + quantise + symbols + histogram
+// ------------------------------------------------------------------------------------------------
+struct I4 { int v[4]; };
+
+__device__ __forceinline__ I4 load4_i16(const int16_t* p) {
+    const uint2 w = *(const uint2*)p;
+    I4 r;
+    r.v[0] = (int)(short)(w.x & 0xFFFF); r.v[1] = (int)(short)(w.x >> 16);
+    r.v[2] = (int)(short)(w.y & 0xFFFF); r.v[3] = (int)(short)(w.y >> 16);
+    return r;
+}
+template <bool EXACT>
+__device__ __forceinline__ I4 lift4(const I4& base, const I4& a, const I4& b, int c) {
+    I4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = wadd(base.v[i], lift_delta<EXACT>(a.v[i], b.v[i], c));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t quant_sym4(const I4& x, int step, uint32_t magic, uint32_t* lh, uint32_t& zeros) {
+    uint32_t packed = 0u;
+    const int hdz = step / 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int val = x.v[i];
+        const int mag = val < 0 ? -val : val;
+        uint32_t s = 0u;
+        if (mag >= step) {  // dead zone = step (Quantizer::new, src/quant.rs:70-75)
+            const uint32_t adj = (uint32_t)(mag - hdz);
+            const uint32_t q = (step == 1) ? adj : __umulhi(adj, magic);
+            // q can be 0 just above the dead zone; to_symbols maps 0 -> 0 (src/quant.rs:557)
+            s = (q == 0u) ? 0u : (((val > 0) ? (2u * q - 1u) : (2u * q)) & 0xFFu);  // `as u8`
+        }
+        if (s == 0u) ++zeros; else atomicAdd(&lh[s], 1u);
+        packed |= s << (8 * i);
+    }
+    return packed;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ mid, uint8_t* __restrict__ sym,
+                                                    uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf, int step,
+                                                    uint32_t magic) {
     __shared__ uint32_t lh[256];
     const int tid = threadIdx.x;
     lh[tid] = 0u;
     __syncthreads();
     const size_t plane = (size_t)d.pw * d.ph;
-    const size_t idx = (size_t)blockIdx.x * 256 + tid;
+    const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
     const int ch = blockIdx.y;
     const int pf = d.pf, half = pf / 2;
-    const bool live = idx < plane;
     uint32_t zeros = 0u;
-    if (live) {
-        int v[MAXF];
-        const int32_t* src = mid + (size_t)ch * pf * plane + idx;
-#pragma unroll
-        for (int t = 0; t < MAXF; ++t) v[t] = (t < pf) ? src[(size_t)t * plane] : 0;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int c = cf.c[k];
-            if ((k & 1) == 0) {
-#pragma unroll
-                for (int i = 0; i < MAXF / 2; ++i) {
-                    if (i < half) {
-                        const int right = (2 * i + 2 < MAXF && 2 * i + 2 < pf) ? v[(2 * i + 2) % MAXF] : v[2 * i];
-                        v[2 * i + 1] += lift_delta<false>(v[2 * i], right, c);
+    if (idx < plane) {
+        const int16_t* src = mid + (size_t)ch * pf * plane + idx;
+        uint32_t* dst = (uint32_t*)(sym + (size_t)ch * pf * plane + idx);
+        const size_t plane4 = plane / 4;
+        // window: raw pair j-1, O1[j-2], E1[j-2], O2[j-3] (9/7); see the derivation in DESIGN.md
+        I4 e0p{}, o0p{}, o1pp{}, e1pp{}, o2ppp{};
+        I4 e0c = load4_i16(src), o0c = load4_i16(src + plane);
+        const int last = (NS == 4) ? half + 1 : half;
+        for (int j = 0; j <= last; ++j) {
+            I4 e0n{}, o0n{};
+            if (j + 1 < half) {  // prefetch pair j+1
+                e0n = load4_i16(src + (size_t)(2 * j + 2) * plane);
+                o0n = load4_i16(src + (size_t)(2 * j + 3) * plane);
+            }
+            if (j >= 1) {
+                I4 o1p, e1p;
+                bool have1 = j <= half;
+                if (have1) {
+                    // P1 for pair j-1: right neighbour is E0[j] or (at the end) E0[j-1] itself
+                    o1p = lift4<false>(o0p, e0p, (j < half) ? e0c : e0p, cf.c[0]);
+                    // U1 for pair j-1: left neighbour is O1[j-2] or (at the start) O1[0]
+                    e1p = lift4<false>(e0p, (j >= 2) ? o1pp : o1p, o1p, cf.c[1]);
+                }
+                if (NS == 2) {
+                    const uint32_t lo = quant_sym4(e1p, step, magic, lh, zeros);
+                    const uint32_t hi = quant_sym4(o1p, step, magic, lh, zeros);
+                    dst[(size_t)(j - 1) * plane4] = lo;
+                    dst[(size_t)(half + j - 1) * plane4] = hi;
+                } else {
+                    if (j >= 2) {
+                        // P2 for pair j-2: right neighbour E1[j-1] or mirror E1[j-2]
+                        const I4 o2pp = lift4<false>(o1pp, e1pp, have1 ? e1p : e1pp, cf.c[2]);
+                        // U2 for pair j-2: left neighbour O2[j-3] or mirror O2[0]
+                        const I4 e2pp = lift4<false>(e1pp, (j >= 3) ? o2ppp : o2pp, o2pp, cf.c[3]);
+                        const uint32_t lo = quant_sym4(e2pp, step, magic, lh, zeros);
+                        const uint32_t hi = quant_sym4(o2pp, step, magic, lh, zeros);
+                        dst[(size_t)(j - 2) * plane4] = lo;
+                        dst[(size_t)(half + j - 2) * plane4] = hi;
+                        o2ppp = o2pp;
                     }
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MAXF / 2; ++i) {
-                    if (i < half) {
-                        const int left = (i > 0) ? v[(2 * i - 1 + MAXF) % MAXF] : v[1];
-                        v[2 * i] += lift_delta<false>(left, v[2 * i + 1], c);
-                    }
-                }
+                if (have1) { o1pp = o1p; e1pp = e1p; }
             }
-        }
-        uint8_t* dst = sym + (size_t)ch * pf * plane + idx;
-        const int hdz = step / 2;
-#pragma unroll
-        for (int t = 0; t < MAXF; ++t) {
-            if (t < pf) {
-                const int val = v[t];
-                const int mag = val < 0 ? -val : val;
-                uint32_t s = 0u;
-                if (mag >= step) {  // dead zone = step (Quantizer::new)
-                    const uint32_t adj = (uint32_t)(mag - hdz);
-                    const uint32_t q = (step == 1) ? adj : __umulhi(adj, magic);
-                    // q can be 0 just above the dead zone ((mag - step/2) / step); to_symbols maps 0 -> 0
-                    s = (q == 0u) ? 0u : ((val > 0) ? (2u * q - 1u) : (2u * q));
-                    s &= 0xFFu;  // `as u8`
-                }
-                const int tt = (t & 1) * half + (t >> 1);
-                dst[(size_t)tt * plane] = (uint8_t)s;
-                if (s == 0u) ++zeros;
-                else atomicAdd(&lh[s], 1u);
-            }
+            e0p = e0c; o0p = o0c;
+            e0c = e0n; o0c = o0n;
         }
     }
     if (zeros) atomicAdd(&lh[0], zeros);
@@ -210,112 +283,192 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int32_t* __restrict__ 
     if (cnt) atomicAdd(&hist[ch * 256 + tid], cnt);
 }
 
-// from_symbols + dequantize + inverse temporal lifting.  Writes frames t < f only.
-template <int NS, int MAXF, bool EXACT>
-__global__ __launch_bounds__(256) void inv_t_kernel(const uint8_t* __restrict__ sym, int32_t* __restrict__ mid,
-                                                    ChunkDims d, Coeffs cf, int step0, int step1, int step2) {
-    const size_t plane = (size_t)d.pw * d.ph;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int ch = blockIdx.y;
-    const int pf = d.pf, half = pf / 2;
-    if (idx >= plane) return;
-    const int step = ch == 0 ? step0 : (ch == 1 ? step1 : step2);
-    int v[MAXF];
-    const uint8_t* src = sym + (size_t)ch * pf * plane + idx;
+// ------------------------------------------------------------------------------------------------
+// K3: from_symbols + dequantize + inverse temporal lifting (stream over pairs); frames t < f only
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ I4 dequant4(uint32_t packed, int step) {
+    I4 r;
 #pragma unroll
-    for (int t = 0; t < MAXF; ++t) {
-        int val = 0;
-        if (t < pf) {
-            const int tt = (t & 1) * half + (t >> 1);  // interleave: v[2i] = low[i], v[2i+1] = high[i]
-            const int s = src[(size_t)tt * plane];
-            const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));  // src/quant.rs:581-587
-            val = (int)((unsigned)q * (unsigned)step);                       // src/quant.rs:104-110
-        }
-        v[t] = val;
+    for (int i = 0; i < 4; ++i) {
+        const int s = (packed >> (8 * i)) & 0xFF;
+        const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));  // src/quant.rs:581-587
+        r.v[i] = (int)((unsigned)q * (unsigned)step);                      // src/quant.rs:104-110
     }
-#pragma unroll
-    for (int k = NS - 1; k >= 0; --k) {
-        const int c = -cf.c[k];  // src/wavelet.rs:167-174
-        if ((k & 1) == 0) {
-#pragma unroll
-            for (int i = 0; i < MAXF / 2; ++i) {
-                if (i < half) {
-                    const int right = (2 * i + 2 < MAXF && 2 * i + 2 < pf) ? v[(2 * i + 2) % MAXF] : v[2 * i];
-                    v[2 * i + 1] = wadd(v[2 * i + 1], lift_delta<EXACT>(v[2 * i], right, c));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MAXF / 2; ++i) {
-                if (i < half) {
-                    const int left = (i > 0) ? v[(2 * i - 1 + MAXF) % MAXF] : v[1];
-                    v[2 * i] = wadd(v[2 * i], lift_delta<EXACT>(left, v[2 * i + 1], c));
-                }
-            }
-        }
-    }
-    int32_t* dst = mid + (size_t)ch * pf * plane + idx;
-#pragma unroll
-    for (int t = 0; t < MAXF; ++t)
-        if (t < (int)d.f) dst[(size_t)t * plane] = v[t];
+    return r;
+}
+template <typename MidT>
+__device__ __forceinline__ void store4(MidT* p, const I4& x);
+template <>
+__device__ __forceinline__ void store4<int32_t>(int32_t* p, const I4& x) {
+    *(int4*)p = make_int4(x.v[0], x.v[1], x.v[2], x.v[3]);
+}
+template <>
+__device__ __forceinline__ void store4<int16_t>(int16_t* p, const I4& x) {
+    uint2 w;
+    w.x = ((uint32_t)x.v[0] & 0xFFFFu) | ((uint32_t)x.v[1] << 16);
+    w.y = ((uint32_t)x.v[2] & 0xFFFFu) | ((uint32_t)x.v[3] << 16);
+    *(uint2*)p = w;
 }
 
-template <int NS, bool EXACT>
-__global__ __launch_bounds__(256) void inv_xy_kernel(const int32_t* __restrict__ mid, uint8_t* __restrict__ rgb,
-                                                     ChunkDims d, Coeffs cf) {
-    constexpr int H = NS;
-    constexpr int EW = TW + 2 * H, EH = TH + 2 * H, EWh = EW / 2, EHh = EH / 2;
-    __shared__ int L[3][EH][EW];
-    const int tid = threadIdx.x;
-    const int gx0 = blockIdx.x * TW, gy0 = blockIdx.y * TH, t = blockIdx.z;
-    const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
-    const int gpx0 = (gx0 - H) / 2, gpy0 = (gy0 - H) / 2;
+template <int NS, bool EXACT, typename MidT>
+__global__ __launch_bounds__(256) void inv_t_kernel(const uint8_t* __restrict__ sym, MidT* __restrict__ mid, ChunkDims d,
+                                                    Coeffs cf, int step0, int step1, int step2) {
+    const size_t plane = (size_t)d.pw * d.ph;
+    const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int ch = blockIdx.y;
+    const int pf = d.pf, half = pf / 2, nf = d.f;
+    if (idx >= plane) return;
+    const int step = ch == 0 ? step0 : (ch == 1 ? step1 : step2);
+    const uint32_t* src = (const uint32_t*)(sym + (size_t)ch * pf * plane + idx);
+    MidT* dst = mid + (size_t)ch * pf * plane + idx;
+    const size_t plane4 = plane / 4;
+    // inverse step order (src/wavelet.rs:167-174): U2', P2', U1', P1' with negated coefficients
+    const int c0 = -cf.c[0], c1 = -cf.c[1], c2 = -cf.c[2], c3 = -cf.c[3];
+    I4 lo_c = dequant4(src[0], step), hi_c = dequant4(src[(size_t)half * plane4], step);  // E2[0], O2[0]
+    I4 o2p{}, e1p{}, o1pp{}, e0pp{};
+    const int last = (NS == 4) ? half + 1 : half;
+    for (int j = 0; j <= last; ++j) {
+        I4 lo_n{}, hi_n{};
+        if (j + 1 < half) {
+            lo_n = dequant4(src[(size_t)(j + 1) * plane4], step);
+            hi_n = dequant4(src[(size_t)(half + j + 1) * plane4], step);
+        }
+        if (NS == 4) {
+            I4 e1c{};
+            const bool havec = j < half;
+            if (havec) e1c = lift4<EXACT>(lo_c, (j >= 1) ? o2p : hi_c, hi_c, c3);        // U2': E1[j]
+            if (j >= 1) {
+                I4 o1p, e0p;
+                const bool have1 = j <= half;
+                if (have1) {
+                    o1p = lift4<EXACT>(o2p, e1p, havec ? e1c : e1p, c2);                 // P2': O1[j-1]
+                    e0p = lift4<EXACT>(e1p, (j >= 2) ? o1pp : o1p, o1p, c1);             // U1': E0[j-1]
+                    if (2 * (j - 1) < nf) store4<MidT>(dst + (size_t)(2 * (j - 1)) * plane, e0p);
+                }
+                if (j >= 2) {
+                    const I4 o0pp = lift4<EXACT>(o1pp, e0pp, have1 ? e0p : e0pp, c0);    // P1': O0[j-2]
+                    if (2 * (j - 2) + 1 < nf) store4<MidT>(dst + (size_t)(2 * (j - 2) + 1) * plane, o0pp);
+                }
+                if (have1) { o1pp = o1p; e0pp = e0p; }
+            }
+            if (havec) { o2p = hi_c; e1p = e1c; }
+        } else {
+            I4 e0c{};
+            const bool havec = j < half;
+            if (havec) {
+                e0c = lift4<EXACT>(lo_c, (j >= 1) ? o2p : hi_c, hi_c, c1);                // U1': E0[j]
+                if (2 * j < nf) store4<MidT>(dst + (size_t)(2 * j) * plane, e0c);
+            }
+            if (j >= 1) {
+                const I4 o0p = lift4<EXACT>(o2p, e1p, havec ? e0c : e1p, c0);            // P1': O0[j-1]
+                if (2 * (j - 1) + 1 < nf) store4<MidT>(dst + (size_t)(2 * (j - 1) + 1) * plane, o0p);
+            }
+            if (havec) { o2p = hi_c; e1p = e0c; }
+        }
+        lo_c = lo_n; hi_c = hi_n;
+    }
+}
 
-    for (int it = tid; it < 3 * EH * EW; it += 256) {
-        const int cc = it % EW, rr = (it / EW) % EH, ch = it / (EW * EH);
-        const int px = cc / EWh, jx = cc % EWh, py = rr / EHh, jy = rr % EHh;
-        const int gxp = gpx0 + jx, gyp = gpy0 + jy;
-        int v = 0;
-        if (gxp >= 0 && gxp < hw && gyp >= 0 && gyp < hh)
-            v = mid[(((size_t)ch * d.pf + t) * ph + (py * hh + gyp)) * pw + (px * hw + gxp)];
-        L[ch][rr][cc] = v;
+// ------------------------------------------------------------------------------------------------
+// K4: inverse spatial transform of one frame tile + colour
+// ------------------------------------------------------------------------------------------------
+constexpr int I_TW = 96, I_TH = 32, I_SEG = 8, I_NSEG = 12, I_THREADS = 384;
+
+template <int NS, bool EDGE, bool EXACT, typename MidT>
+__global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restrict__ mid, uint8_t* __restrict__ rgb,
+                                                           ChunkDims d, Coeffs cf, int aligned) {
+    constexpr int H = NS;
+    constexpr int ER = I_TH + 2 * H;        // rows incl. halo
+    constexpr int EC = I_TW + 2 * H;        // columns incl. halo (104 / 100)
+    constexpr int ECh = EC / 2;
+    constexpr int LW = 104;                 // LDS row pitch
+    constexpr int NL = I_SEG + 2 * H;       // samples lifted per segment
+    __shared__ int lds[3 * ER * LW];
+    const int tid = threadIdx.x;
+    const int gx0 = blockIdx.x * I_TW, gy0 = blockIdx.y * I_TH, t = blockIdx.z;
+    const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
+    const int gpx0 = (gx0 - H) / 2;  // first column pair of the extended tile (may be negative)
+
+    // stage A: one thread per (extended column, channel): inverse column lifting in registers
+    if (tid < 3 * EC) {
+        const int ch = tid / EC, xq = tid % EC;
+        const int par = xq / ECh, j = xq % ECh;
+        const int gxp = gpx0 + j;
+        if (!EDGE || (gxp >= 0 && gxp < hw)) {
+            int v[ER];
+            const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
+            const int gy_s = gy0 - H;
+#pragma unroll
+            for (int k = 0; k < ER; ++k) {
+                const int gy = gy_s + k;
+                int val = 0;
+                if (!EDGE || (gy >= 0 && gy < ph)) {
+                    const int yy = (gy & 1) * hh + (gy >> 1);
+                    val = (int)src[(size_t)yy * pw];
+                }
+                v[k] = val;
+            }
+            lift_regs<ER, NS, EDGE, EXACT, true>(v, cf, gy_s, ph);
+            int* L = lds + (ch * ER) * LW + xq;
+#pragma unroll
+            for (int k = 0; k < ER; ++k) L[k * LW] = v[k];
+        }
     }
     __syncthreads();
 
-    // columns first, then rows (src/wavelet.rs:465-482); steps reversed with negated coefficients
-    if (NS == 4) {
-        tile_lift_step<EW, EH, EXACT, false, 1>(L, -cf.c[3], gpy0, ph, tid);
-        tile_lift_step<EW, EH, EXACT, true, 1>(L, -cf.c[2], gpy0, ph, tid);
-    }
-    tile_lift_step<EW, EH, EXACT, false, 1>(L, -cf.c[1], gpy0, ph, tid);
-    tile_lift_step<EW, EH, EXACT, true, 1>(L, -cf.c[0], gpy0, ph, tid);
-    if (NS == 4) {
-        tile_lift_step<EW, EH, EXACT, false, 0>(L, -cf.c[3], gpx0, pw, tid);
-        tile_lift_step<EW, EH, EXACT, true, 0>(L, -cf.c[2], gpx0, pw, tid);
-    }
-    tile_lift_step<EW, EH, EXACT, false, 0>(L, -cf.c[1], gpx0, pw, tid);
-    tile_lift_step<EW, EH, EXACT, true, 0>(L, -cf.c[0], gpx0, pw, tid);
-
-    for (int it = tid; it < TH * TW; it += 256) {
-        const int lx = it % TW, ly = it / TW;
-        const int gx = gx0 + lx, gy = gy0 + ly;
-        if (gx < (int)d.w && gy < (int)d.h) {
-            const int rr = ((ly + H) & 1) * EHh + ((ly + H) >> 1), cc = ((lx + H) & 1) * EWh + ((lx + H) >> 1);
-            // `as i16` (src/pipeline.rs:608) then wrapping i16 arithmetic (src/color.rs:266-273)
-            const short yv = (short)L[0][rr][cc], co = (short)L[1][rr][cc], cg = (short)L[2][rr][cc];
-            const short tt = (short)(yv - (short)(cg >> 1));
-            const short g = (short)(cg + tt);
-            const short b = (short)(tt - (short)(co >> 1));
-            const short r = (short)(co + b);
-            uint8_t* p = rgb + (((size_t)t * d.h + gy) * d.w + gx) * 3;
-            p[0] = (uint8_t)min(max((int)r, 0), 255);
-            p[1] = (uint8_t)min(max((int)g, 0), 255);
-            p[2] = (uint8_t)min(max((int)b, 0), 255);
+    // stage B: one thread per (interior row, 8-pixel segment): inverse row lifting + colour
+    {
+        const int r = tid / I_NSEG, s = tid % I_NSEG;  // 384 = 32 * 12
+        const int gy = gy0 + r;
+        const int gxs = gx0 + s * I_SEG;               // first interior pixel of the segment
+        if (gy < (int)d.h && gxs < (int)d.w) {
+            int y[NL], co[NL], cg[NL];
+            const int lx0 = s * I_SEG;                 // offset of sample 0 inside the extended tile (even)
+            const int* L0 = lds + (0 * ER + r + H) * LW;
+            const int* L1 = lds + (1 * ER + r + H) * LW;
+            const int* L2 = lds + (2 * ER + r + H) * LW;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int lx = lx0 + k;
+                const int q = (lx & 1) * ECh + (lx >> 1);
+                y[k] = L0[q]; co[k] = L1[q]; cg[k] = L2[q];
+            }
+            const int g0 = gxs - H;
+            lift_regs<NL, NS, EDGE, EXACT, true>(y, cf, g0, pw);
+            lift_regs<NL, NS, EDGE, EXACT, true>(co, cf, g0, pw);
+            lift_regs<NL, NS, EDGE, EXACT, true>(cg, cf, g0, pw);
+            uint8_t out[I_SEG * 3];
+#pragma unroll
+            for (int k = 0; k < I_SEG; ++k) {
+                // `as i16` (src/pipeline.rs:608) then wrapping i16 arithmetic (src/color.rs:266-273)
+                const short yv = (short)y[H + k], c_o = (short)co[H + k], c_g = (short)cg[H + k];
+                const short tt = (short)(yv - (short)(c_g >> 1));
+                const short g = (short)(c_g + tt);
+                const short b = (short)(tt - (short)(c_o >> 1));
+                const short rr = (short)(c_o + b);
+                out[3 * k] = (uint8_t)min(max((int)rr, 0), 255);
+                out[3 * k + 1] = (uint8_t)min(max((int)g, 0), 255);
+                out[3 * k + 2] = (uint8_t)min(max((int)b, 0), 255);
+            }
+            uint8_t* p = rgb + (((size_t)t * d.h + gy) * d.w + gxs) * 3;
+            if (aligned && gxs + I_SEG <= (int)d.w) {
+                uint32_t* p4 = (uint32_t*)p;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    p4[i] = (uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) |
+                            ((uint32_t)out[4 * i + 3] << 24);
+            } else {
+#pragma unroll
+                for (int k = 0; k < I_SEG; ++k)
+                    if (gxs + k < (int)d.w) { p[3 * k] = out[3 * k]; p[3 * k + 1] = out[3 * k + 1]; p[3 * k + 2] = out[3 * k + 2]; }
+            }
         }
     }
 }
 
-// ----------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
 
 static Coeffs to_coeffs(const LiftSteps& s) {
     Coeffs c{};
@@ -323,61 +476,84 @@ static Coeffs to_coeffs(const LiftSteps& s) {
     return c;
 }
 
-template <int NS>
-static void fwd_t_dispatch(const int32_t* mid, uint8_t* sym, uint32_t* hist, const ChunkDims& d, Coeffs cf,
-                           int step, uint32_t magic, hipStream_t st) {
-    const size_t plane = (size_t)d.pw * d.ph;
-    dim3 grid((unsigned)((plane + 255) / 256), 3), block(256);
-    if (d.pf <= 8) hipLaunchKernelGGL((fwd_t_kernel<NS, 8>), grid, block, 0, st, mid, sym, hist, d, cf, step, magic);
-    else if (d.pf <= 16) hipLaunchKernelGGL((fwd_t_kernel<NS, 16>), grid, block, 0, st, mid, sym, hist, d, cf, step, magic);
-    else if (d.pf <= 32) hipLaunchKernelGGL((fwd_t_kernel<NS, 32>), grid, block, 0, st, mid, sym, hist, d, cf, step, magic);
-    else hipLaunchKernelGGL((fwd_t_kernel<NS, 64>), grid, block, 0, st, mid, sym, hist, d, cf, step, magic);
+template <typename K>
+static bool set_dyn_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
+// Tiles strictly inside the frame (no clamping, no mirroring) run the EDGE=false instance, launched as
+// one interior rectangle of tiles; the four border strips run EDGE=true.
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
                               int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
-    if (d.pf > 64 || step < 1 || step > 64) return false;
+    if (step < 1 || step > 64) return false;
+    if (d.pf > 65535u) return false;
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
-    dim3 grid((d.pw + TW - 1) / TW, (d.ph + TH - 1) / TH, d.pf), block(256);
-    if (grid.y > 65535u || grid.z > 65535u) return false;
-    // adj * step < 2^32 (|coefficient| < 2^15 from u8 input, step <= 64) makes umulhi(adj, ceil(2^32/step)) exact
-    const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
-    if (ls.n == 4) {
-        hipLaunchKernelGGL((fwd_xy_kernel<4>), grid, block, 0, st, d_rgb, d_mid, d, cf);
-        fwd_t_dispatch<4>(d_mid, d_sym, d_hist, d, cf, step, magic, st);
+    int16_t* mid = (int16_t*)d_mid;
+    const unsigned nx = (d.pw + F_TW - 1) / F_TW, ny = (d.ph + F_TH - 1) / F_TH;
+    if (ny > 65535u) return false;
+    const int aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
+    // a tile is interior when its loaded range [gx0-4, gx0+128+4) x [gy0-H, gy0+40+H) lies inside w x h
+    auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * F_TW + F_TW + 4) <= d.w; };
+    auto interior_y = [&](unsigned by) { return by >= 1 && (by * F_TH + F_TH + 4) <= d.h; };
+    unsigned ix0 = 1, ix1 = 1, iy0 = 1, iy1 = 1;
+    while (ix1 < nx && interior_x(ix1)) ++ix1;
+    while (iy1 < ny && interior_y(iy1)) ++iy1;
+    const bool has_interior = ix1 > ix0 && iy1 > iy0;
+    const size_t lds4 = (size_t)3 * (F_TH + 8) * F_TW * sizeof(int), lds2 = (size_t)3 * (F_TH + 4) * F_TW * sizeof(int);
+    dim3 block(F_THREADS);
+    auto run = [&](bool edge, unsigned bx0, unsigned by0, unsigned cx, unsigned cy) {
+        if (cx == 0 || cy == 0) return;
+        dim3 grid(cx, cy, d.pf);
+        if (ls.n == 4) {
+            if (edge) { set_dyn_lds(fwd_xy_kernel<4, true>, lds4); hipLaunchKernelGGL((fwd_xy_kernel<4, true>), grid, block, lds4, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
+            else { set_dyn_lds(fwd_xy_kernel<4, false>, lds4); hipLaunchKernelGGL((fwd_xy_kernel<4, false>), grid, block, lds4, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
+        } else {
+            if (edge) { set_dyn_lds(fwd_xy_kernel<2, true>, lds2); hipLaunchKernelGGL((fwd_xy_kernel<2, true>), grid, block, lds2, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
+            else { set_dyn_lds(fwd_xy_kernel<2, false>, lds2); hipLaunchKernelGGL((fwd_xy_kernel<2, false>), grid, block, lds2, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
+        }
+    };
+    if (has_interior) {
+        run(false, ix0, iy0, ix1 - ix0, iy1 - iy0);
+        run(true, 0, 0, nx, iy0);                       // top strip
+        run(true, 0, iy1, nx, ny - iy1);                // bottom strip
+        run(true, 0, iy0, ix0, iy1 - iy0);              // left strip
+        run(true, ix1, iy0, nx - ix1, iy1 - iy0);       // right strip
     } else {
-        hipLaunchKernelGGL((fwd_xy_kernel<2>), grid, block, 0, st, d_rgb, d_mid, d, cf);
-        fwd_t_dispatch<2>(d_mid, d_sym, d_hist, d, cf, step, magic, st);
+        run(true, 0, 0, nx, ny);
     }
+    const size_t plane = (size_t)d.pw * d.ph;
+    const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
+    dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
+    if (ls.n == 4) hipLaunchKernelGGL((fwd_t_kernel<4>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+    else hipLaunchKernelGGL((fwd_t_kernel<2>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
     return true;
 }
 
-template <int NS, bool EXACT>
-static void inv_dispatch(const uint8_t* sym, int32_t* mid, uint8_t* rgb, const ChunkDims& d, Coeffs cf,
-                         const int32_t step[3], hipStream_t st) {
+template <int NS, bool EXACT, typename MidT>
+static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkDims& d, Coeffs cf, const int32_t step[3],
+                       hipStream_t st) {
     const size_t plane = (size_t)d.pw * d.ph;
-    dim3 gt((unsigned)((plane + 255) / 256), 3), block(256);
-    if (d.pf <= 8) hipLaunchKernelGGL((inv_t_kernel<NS, 8, EXACT>), gt, block, 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
-    else if (d.pf <= 16) hipLaunchKernelGGL((inv_t_kernel<NS, 16, EXACT>), gt, block, 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
-    else if (d.pf <= 32) hipLaunchKernelGGL((inv_t_kernel<NS, 32, EXACT>), gt, block, 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
-    else hipLaunchKernelGGL((inv_t_kernel<NS, 64, EXACT>), gt, block, 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
-    dim3 gxy((d.pw + TW - 1) / TW, (d.ph + TH - 1) / TH, d.f);
-    hipLaunchKernelGGL((inv_xy_kernel<NS, EXACT>), gxy, block, 0, st, mid, rgb, d, cf);
+    dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
+    hipLaunchKernelGGL((inv_t_kernel<NS, EXACT, MidT>), gt, dim3(256), 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
+    const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + I_TH - 1) / I_TH;
+    const int aligned = (d.w % 4 == 0) && ((((uintptr_t)rgb) & 3u) == 0u);
+    dim3 grid(nx, ny, d.f);
+    // the inverse tiles are few enough per frame that one EDGE=true instance serves all of them
+    hipLaunchKernelGGL((inv_xy_kernel<NS, true, EXACT, MidT>), grid, dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned);
 }
 
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
                               bool exact, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
-    if (d.pf > 64) return false;
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
-    if ((d.ph + TH - 1) / TH > 65535u || d.f > 65535u) return false;
+    if ((d.h + I_TH - 1) / I_TH > 65535u || d.f > 65535u) return false;
     if (ls.n == 4) {
-        if (exact) inv_dispatch<4, true>(d_sym, d_mid, d_rgb, d, cf, step, st);
-        else inv_dispatch<4, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        if (exact) inv_launch<4, true, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        else inv_launch<4, false, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
     } else {
-        if (exact) inv_dispatch<2, true>(d_sym, d_mid, d_rgb, d, cf, step, st);
-        else inv_dispatch<2, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        if (exact) inv_launch<2, true, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        else inv_launch<2, false, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
     }
     return true;
 }
