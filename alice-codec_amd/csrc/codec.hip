@@ -268,14 +268,19 @@ int checked_pixel_count(uint64_t w, uint64_t h, uint64_t f, uint64_t* out) {
 
 inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-// Rigorous magnitude bound through the inverse 3-D lifting: true when 32-bit products are safe.
-bool inverse_fast_ok(int wavelet, const int32_t step[3]) {
+// Rigorous magnitude bound through the inverse 3-D lifting.  Symbols are u8, so |q| <= 128 and every
+// dequantised sample is at most 128 * |step|; each lifting step adds at most (2 * other * |c| + 4096) / 8192 + 1.
+// fast: 32-bit (24 x 24-bit) products are exact everywhere.  mid16: additionally every value after the
+// temporal pass fits i16, so the intermediate can be stored in 16 bits.
+struct InverseBounds { bool fast; bool mid16; };
+InverseBounds inverse_bounds(int wavelet, const int32_t step[3]) {
     const LiftSteps ls = lift_steps(wavelet);
     long double worst = 0;
     for (int c = 0; c < 3; ++c) {
         long double a = 128.0L * fabsl((long double)step[c]);
         if (a > worst) worst = a;
     }
+    InverseBounds r{true, false};
     long double m = worst;  // bound on every sample
     for (int pass = 0; pass < 3; ++pass) {
         long double me = m, mo = m;
@@ -283,13 +288,15 @@ bool inverse_fast_ok(int wavelet, const int32_t step[3]) {
             const long double cabs = fabsl((long double)ls.coeff[k]);
             long double& target = (k & 1) == 0 ? mo : me;
             const long double other = (k & 1) == 0 ? me : mo;
-            if (2 * other * cabs + 4096 >= 2147483647.0L) return false;
+            // v_mul_i24 operands: |a + b| < 2^23; product + rounding below 2^31
+            if (2 * other >= 8388607.0L || 2 * other * cabs + 4096 >= 2147483647.0L) { r.fast = false; return r; }
             target = target + (2 * other * cabs + 4096) / 8192 + 1;
-            if (target >= 1073741824.0L) return false;
+            if (target >= 1073741824.0L) { r.fast = false; return r; }
         }
         m = me > mo ? me : mo;
+        if (pass == 0) r.mid16 = m <= 32767.0L;
     }
-    return true;
+    return r;
 }
 
 struct EncodeWork {
@@ -306,7 +313,7 @@ int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks, uint64_t 
     TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
     TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
     TRY(w.tables.alloc((size_t)n_chunks * 3 * sizeof(RansTable)));
-    TRY(w.streams.alloc((size_t)n_chunks * 3 * cap));
+    TRY(w.streams.alloc((size_t)n_chunks * 3 * cap + 256));  // slack: the compaction copy reads whole dwords
     TRY(w.results.alloc((size_t)n_chunks * 3 * sizeof(RansResult)));
     TRY(w.alc.alloc((size_t)n_chunks * w.alc_stride));
     TRY(w.sizes.alloc((size_t)n_chunks * sizeof(unsigned long long)));
@@ -462,10 +469,10 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
     if (evs) HIP_TRY(hipEventRecord(evs->ev[6], st));
     for (int b = 0; b < B; ++b) {
         int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
-        const bool exact = !inverse_fast_ok(headers[b].wavelet, step);
+        const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
         const uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
         uint8_t* rgb = d_rgb_out + (size_t)b * d.n_pixels * 3;
-        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, exact, w.mid.as<int32_t>(), rgb, st))
+        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, w.mid.as<int32_t>(), rgb, st))
             TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, rgb, st));
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[7], st));

@@ -359,12 +359,32 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(uint8_t* __restric
                                                               const RansResult* __restrict__ res) {
     const int chunk = blockIdx.y;
     uint8_t* dst = alc + (size_t)chunk * alc_stride + kAlcHeaderBytes;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, nthreads = (unsigned long long)gridDim.x * 256;
     for (int c = 0; c < 3; ++c) {
         const unsigned long long len = res[chunk * 3 + c].len;
         const uint8_t* src = streams + ((size_t)chunk * 3 + c) * cap + (cap - len);
-        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < len;
-             i += (unsigned long long)gridDim.x * 256)
-            dst[i] = src[i];
+        // bytes up to the first 16-byte boundary of dst, then 16 B stores fed by (possibly unaligned) 4 B loads
+        unsigned long long head = (16u - (unsigned)((uintptr_t)dst & 15u)) & 15u;
+        if (head > len) head = len;
+        for (unsigned long long i = tid; i < head; i += nthreads) dst[i] = src[i];
+        const unsigned long long nvec = (len - head) / 16;
+        const unsigned mis = (unsigned)((uintptr_t)(src + head) & 3u);
+        for (unsigned long long v = tid; v < nvec; v += nthreads) {
+            const uint8_t* sp = src + head + v * 16;
+            uint32_t w[4];
+            if (mis == 0) {
+                const uint32_t* s4 = (const uint32_t*)sp;
+                w[0] = s4[0]; w[1] = s4[1]; w[2] = s4[2]; w[3] = s4[3];
+            } else {
+                const uint32_t* s4 = (const uint32_t*)(sp - mis);
+                uint32_t t0 = s4[0], t1 = s4[1], t2 = s4[2], t3 = s4[3], t4 = s4[4];
+                const unsigned sh = mis * 8;
+                w[0] = (t0 >> sh) | (t1 << (32 - sh)); w[1] = (t1 >> sh) | (t2 << (32 - sh));
+                w[2] = (t2 >> sh) | (t3 << (32 - sh)); w[3] = (t3 >> sh) | (t4 << (32 - sh));
+            }
+            *(uint4*)(dst + head + v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        for (unsigned long long i = head + nvec * 16 + tid; i < len; i += nthreads) dst[i] = src[i];
         dst += len;
     }
 }
@@ -379,7 +399,7 @@ void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& 
 void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, const uint8_t* d_streams, uint64_t cap,
                             const RansResult* d_results, int n_chunks, hipStream_t st) {
     if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(compact_streams_kernel, dim3(512, n_chunks), dim3(256), 0, st, d_alc,
+    hipLaunchKernelGGL(compact_streams_kernel, dim3(1024, n_chunks), dim3(256), 0, st, d_alc,
                        (unsigned long long)alc_stride, d_streams, (unsigned long long)cap, d_results);
 }
 

@@ -37,12 +37,28 @@ __device__ __forceinline__ int lift_delta(int a, int b, int c) {
         const int avg = (int)((unsigned)a + (unsigned)b);
         return (int)(((long long)avg * (long long)c + 4096ll) >> 13);
     } else {
-        return ((a + b) * c + 4096) >> 13;
+        // callers guarantee |a + b| < 2^23 and |(a + b) * c| < 2^31 (forward: u8 input; inverse: host bound
+        // check), so the full-rate 24-bit multiply-add is exact
+        return (__mul24(a + b, c) + 4096) >> 13;
     }
 }
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 
 struct Coeffs { int c[4]; };
+struct TileMap { int nx, ny, ix0, ix1, iy0, iy1; };
+
+// XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an
+// L2), while neighbouring tiles share halo rows/columns and 128-byte lines.  Launch a 1-D grid padded
+// to a multiple of 8 and give XCD k the k-th contiguous eighth of the logical tile sequence, so a
+// tile's neighbours hit in the same L2 (measured before: 2.0x / 2.4x HBM over-fetch in the forward /
+// inverse tile kernels; placement affects speed only, never results).
+__device__ __forceinline__ unsigned xcd_logical_block(unsigned total) {
+    const unsigned b = blockIdx.x;
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned l = (b & 7u) * per_xcd + (b >> 3);
+    return l < total ? l : 0xFFFFFFFFu;
+}
+static inline unsigned xcd_grid(unsigned long long total) { return (unsigned)(((total + 7) / 8) * 8); }
 
 // ------------------------------------------------------------------------------------------------
 // In-register 1-D lifting of N consecutive samples (v[0] has even global index g0).
@@ -80,11 +96,13 @@ __device__ __forceinline__ void lift_regs(int (&v)[N], const Coeffs& cf, int g0,
 // K1: forward spatial transform of one frame tile
 // ------------------------------------------------------------------------------------------------
 constexpr int F_TW = 128, F_TH = 40, F_SEG = 16, F_NSEG = 8, F_THREADS = 384;
+constexpr int F_LP = F_TW / 2 + 1;  // LDS row pitch in dwords (packed i16 pairs); odd pitch keeps stage-A stores at <= 2-way conflicts
 
 template <int NS, bool EDGE>
 __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __restrict__ rgb, int16_t* __restrict__ mid,
-                                                                  ChunkDims d, Coeffs cf, int aligned, int bx0, int by0) {
-    // (bx0, by0): tile origin of the launch region (interior rectangle or one of the border strips)
+                                                                  ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
+    // interior launch: a rectangle of tiles at (ix0, iy0); border launch: one linear grid over the
+    // four border strips (top, bottom, left, right of the interior rectangle)
     constexpr int H = NS;
     constexpr int ER = F_TH + 2 * H;
     constexpr int SE = F_SEG + 8;
@@ -92,7 +110,23 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
     constexpr int NL = F_SEG + 2 * H;
     extern __shared__ int lds[];
     const int tid = threadIdx.x;
-    const int gx0 = (blockIdx.x + bx0) * F_TW, gy0 = (blockIdx.y + by0) * F_TH, t = blockIdx.z;
+    int bx, by, t;
+    {
+        const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
+        const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
+        const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
+        const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
+        const unsigned l = xcd_logical_block(per_frame * d.pf);
+        if (l == 0xFFFFFFFFu) return;
+        t = (int)(l / per_frame);
+        int i = (int)(l % per_frame);
+        if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
+        else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
+        else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
+        else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
+        else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
+    }
+    const int gx0 = bx * F_TW, gy0 = by * F_TH;
     const int pw = d.pw, ph = d.ph;
     const int st = min(t, (int)d.f - 1);
 
@@ -104,7 +138,7 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             const int gxs = gx0 - 4 + s * F_SEG;
             const uint8_t* row = rgb + ((size_t)st * d.h + sy) * d.w * 3;
             int y[SE], co[SE], cg[SE];
-            if (!EDGE && aligned) {
+            if (aligned && (!EDGE || (gxs >= 0 && gxs + SE <= (int)d.w))) {
                 const uint32_t* p4 = (const uint32_t*)(row + (ptrdiff_t)gxs * 3);
                 uint32_t wd[18];
 #pragma unroll
@@ -140,14 +174,20 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             lift_regs<NL, NS, EDGE, false, false>(ly, cf, g0, pw);
             lift_regs<NL, NS, EDGE, false, false>(lco, cf, g0, pw);
             lift_regs<NL, NS, EDGE, false, false>(lcg, cf, g0, pw);
-            int* L0 = lds + (0 * ER + r) * F_TW;
-            int* L1 = lds + (1 * ER + r) * F_TW;
-            int* L2 = lds + (2 * ER + r) * F_TW;
+            // interior 16 samples -> LDS row r as packed i16 pairs (values stay below 2^13 after the row pass):
+            // dword q of a row holds deinterleaved positions (2q, 2q+1); evens of segment s start at
+            // position s*8, odds at 64 + s*8
+            int* L0 = lds + (0 * ER + r) * F_LP;
+            int* L1 = lds + (1 * ER + r) * F_LP;
+            int* L2 = lds + (2 * ER + r) * F_LP;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                L0[s * 8 + j] = ly[H + 2 * j];       L0[64 + s * 8 + j] = ly[H + 2 * j + 1];
-                L1[s * 8 + j] = lco[H + 2 * j];      L1[64 + s * 8 + j] = lco[H + 2 * j + 1];
-                L2[s * 8 + j] = lcg[H + 2 * j];      L2[64 + s * 8 + j] = lcg[H + 2 * j + 1];
+            for (int j = 0; j < 4; ++j) {
+                L0[s * 4 + j] = (ly[H + 4 * j] & 0xFFFF) | (ly[H + 4 * j + 2] << 16);
+                L0[32 + s * 4 + j] = (ly[H + 4 * j + 1] & 0xFFFF) | (ly[H + 4 * j + 3] << 16);
+                L1[s * 4 + j] = (lco[H + 4 * j] & 0xFFFF) | (lco[H + 4 * j + 2] << 16);
+                L1[32 + s * 4 + j] = (lco[H + 4 * j + 1] & 0xFFFF) | (lco[H + 4 * j + 3] << 16);
+                L2[s * 4 + j] = (lcg[H + 4 * j] & 0xFFFF) | (lcg[H + 4 * j + 2] << 16);
+                L2[32 + s * 4 + j] = (lcg[H + 4 * j + 1] & 0xFFFF) | (lcg[H + 4 * j + 3] << 16);
             }
         }
     }
@@ -159,9 +199,10 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
         const int hw = pw / 2, hh = ph / 2;
         if (!EDGE || gxp < hw) {
             int v[ER];
-            const int* L = lds + (ch * ER) * F_TW + xq;
+            const int* L = lds + (ch * ER) * F_LP + (xq >> 1);
+            const int sh = (xq & 1) * 16;
 #pragma unroll
-            for (int r = 0; r < ER; ++r) v[r] = L[r * F_TW];
+            for (int r = 0; r < ER; ++r) v[r] = (int)(short)(L[r * F_LP] >> sh);
             lift_regs<ER, NS, EDGE, false, false>(v, cf, gy0 - H, ph);
             int16_t* out = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
 #pragma unroll
@@ -197,7 +238,13 @@ __device__ __forceinline__ I4 lift4(const I4& base, const I4& a, const I4& b, in
     return r;
 }
 
-__device__ __forceinline__ uint32_t quant_sym4(const I4& x, int step, uint32_t magic, uint32_t* lh, uint32_t& zeros) {
+// Histogram bins in LDS: 8 replicas of the 256 bins (replica = lane & 7) cut same-address atomics
+// eightfold; a zero symbol (45-90 % of the data) goes to a slot private to its thread instead, so the
+// add is unconditional (no exec-mask branch) and conflict-free.  Zeros are recovered as total - nonzero.
+constexpr int kHistReplicas = 8;
+constexpr int kHistWords = kHistReplicas * 256 + 256;
+
+__device__ __forceinline__ uint32_t quant_sym4(const I4& x, int step, uint32_t magic, uint32_t* lh, int rep_base, int dummy) {
     uint32_t packed = 0u;
     const int hdz = step / 2;
 #pragma unroll
@@ -211,7 +258,7 @@ __device__ __forceinline__ uint32_t quant_sym4(const I4& x, int step, uint32_t m
             // q can be 0 just above the dead zone; to_symbols maps 0 -> 0 (src/quant.rs:557)
             s = (q == 0u) ? 0u : (((val > 0) ? (2u * q - 1u) : (2u * q)) & 0xFFu);  // `as u8`
         }
-        if (s == 0u) ++zeros; else atomicAdd(&lh[s], 1u);
+        atomicAdd(&lh[s ? (rep_base + (int)s) : dummy], 1u);
         packed |= s << (8 * i);
     }
     return packed;
@@ -221,28 +268,33 @@ template <int NS>
 __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ mid, uint8_t* __restrict__ sym,
                                                     uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf, int step,
                                                     uint32_t magic) {
-    __shared__ uint32_t lh[256];
+    __shared__ uint32_t lh[kHistWords];
     const int tid = threadIdx.x;
-    lh[tid] = 0u;
+    for (int i = tid; i < kHistWords; i += 256) lh[i] = 0u;
     __syncthreads();
     const size_t plane = (size_t)d.pw * d.ph;
     const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
     const int ch = blockIdx.y;
     const int pf = d.pf, half = pf / 2;
-    uint32_t zeros = 0u;
+    const int rep_base = (tid & (kHistReplicas - 1)) * 256, dummy = kHistReplicas * 256 + tid;
+    uint32_t emitted = 0u;
     if (idx < plane) {
+        emitted = 4u * (uint32_t)pf;
         const int16_t* src = mid + (size_t)ch * pf * plane + idx;
         uint32_t* dst = (uint32_t*)(sym + (size_t)ch * pf * plane + idx);
         const size_t plane4 = plane / 4;
         // window: raw pair j-1, O1[j-2], E1[j-2], O2[j-3] (9/7); see the derivation in DESIGN.md
         I4 e0p{}, o0p{}, o1pp{}, e1pp{}, o2ppp{};
         I4 e0c = load4_i16(src), o0c = load4_i16(src + plane);
+        I4 e0n{}, o0n{};
+        if (1 < half) { e0n = load4_i16(src + (size_t)2 * plane); o0n = load4_i16(src + (size_t)3 * plane); }
         const int last = (NS == 4) ? half + 1 : half;
+#pragma unroll 2
         for (int j = 0; j <= last; ++j) {
-            I4 e0n{}, o0n{};
-            if (j + 1 < half) {  // prefetch pair j+1
-                e0n = load4_i16(src + (size_t)(2 * j + 2) * plane);
-                o0n = load4_i16(src + (size_t)(2 * j + 3) * plane);
+            I4 e0nn{}, o0nn{};
+            if (j + 2 < half) {  // prefetch pair j+2
+                e0nn = load4_i16(src + (size_t)(2 * j + 4) * plane);
+                o0nn = load4_i16(src + (size_t)(2 * j + 5) * plane);
             }
             if (j >= 1) {
                 I4 o1p, e1p;
@@ -254,8 +306,8 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
                     e1p = lift4<false>(e0p, (j >= 2) ? o1pp : o1p, o1p, cf.c[1]);
                 }
                 if (NS == 2) {
-                    const uint32_t lo = quant_sym4(e1p, step, magic, lh, zeros);
-                    const uint32_t hi = quant_sym4(o1p, step, magic, lh, zeros);
+                    const uint32_t lo = quant_sym4(e1p, step, magic, lh, rep_base, dummy);
+                    const uint32_t hi = quant_sym4(o1p, step, magic, lh, rep_base, dummy);
                     dst[(size_t)(j - 1) * plane4] = lo;
                     dst[(size_t)(half + j - 1) * plane4] = hi;
                 } else {
@@ -264,8 +316,8 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
                         const I4 o2pp = lift4<false>(o1pp, e1pp, have1 ? e1p : e1pp, cf.c[2]);
                         // U2 for pair j-2: left neighbour O2[j-3] or mirror O2[0]
                         const I4 e2pp = lift4<false>(e1pp, (j >= 3) ? o2ppp : o2pp, o2pp, cf.c[3]);
-                        const uint32_t lo = quant_sym4(e2pp, step, magic, lh, zeros);
-                        const uint32_t hi = quant_sym4(o2pp, step, magic, lh, zeros);
+                        const uint32_t lo = quant_sym4(e2pp, step, magic, lh, rep_base, dummy);
+                        const uint32_t hi = quant_sym4(o2pp, step, magic, lh, rep_base, dummy);
                         dst[(size_t)(j - 2) * plane4] = lo;
                         dst[(size_t)(half + j - 2) * plane4] = hi;
                         o2ppp = o2pp;
@@ -275,12 +327,21 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
             }
             e0p = e0c; o0p = o0c;
             e0c = e0n; o0c = o0n;
+            e0n = e0nn; o0n = o0nn;
         }
     }
-    if (zeros) atomicAdd(&lh[0], zeros);
     __syncthreads();
-    const uint32_t cnt = lh[tid];
-    if (cnt) atomicAdd(&hist[ch * 256 + tid], cnt);
+    // fold the replicas; bin 0 = symbols emitted by this block - nonzero symbols
+    __shared__ uint32_t tot_sh, nz_sh;
+    if (tid == 0) { tot_sh = 0u; nz_sh = 0u; }
+    __syncthreads();
+    uint32_t cnt = 0u;
+#pragma unroll
+    for (int r = 0; r < kHistReplicas; ++r) cnt += lh[r * 256 + tid];
+    if (emitted) atomicAdd(&tot_sh, emitted);
+    if (tid != 0 && cnt) { atomicAdd(&nz_sh, cnt); atomicAdd(&hist[ch * 256 + tid], cnt); }
+    __syncthreads();
+    if (tid == 0 && tot_sh > nz_sh) atomicAdd(&hist[ch * 256], tot_sh - nz_sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -381,11 +442,15 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
     constexpr int ER = I_TH + 2 * H;        // rows incl. halo
     constexpr int EC = I_TW + 2 * H;        // columns incl. halo (104 / 100)
     constexpr int ECh = EC / 2;
-    constexpr int LW = 104;                 // LDS row pitch
+    constexpr int LW = 105;                 // LDS row pitch (odd: stage-B reads stay at <= 2-way conflicts)
     constexpr int NL = I_SEG + 2 * H;       // samples lifted per segment
     __shared__ int lds[3 * ER * LW];
     const int tid = threadIdx.x;
-    const int gx0 = blockIdx.x * I_TW, gy0 = blockIdx.y * I_TH, t = blockIdx.z;
+    const unsigned ntx = (d.w + I_TW - 1) / I_TW, nty = (d.h + I_TH - 1) / I_TH;
+    const unsigned lb = xcd_logical_block(ntx * nty * d.f);
+    if (lb == 0xFFFFFFFFu) return;
+    const int t = (int)(lb / (ntx * nty));
+    const int gx0 = (int)((lb % (ntx * nty)) % ntx) * I_TW, gy0 = (int)((lb % (ntx * nty)) / ntx) * I_TH;
     const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
     const int gpx0 = (gx0 - H) / 2;  // first column pair of the extended tile (may be negative)
 
@@ -486,12 +551,11 @@ static bool set_dyn_lds(K kernel, size_t bytes) {
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
                               int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
     if (step < 1 || step > 64) return false;
-    if (d.pf > 65535u) return false;
+    if ((unsigned long long)((d.pw + F_TW - 1) / F_TW) * ((d.ph + F_TH - 1) / F_TH) * d.pf > 0x7FFFFFF0ull) return false;
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
     int16_t* mid = (int16_t*)d_mid;
     const unsigned nx = (d.pw + F_TW - 1) / F_TW, ny = (d.ph + F_TH - 1) / F_TH;
-    if (ny > 65535u) return false;
     const int aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
     // a tile is interior when its loaded range [gx0-4, gx0+128+4) x [gy0-H, gy0+40+H) lies inside w x h
     auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * F_TW + F_TW + 4) <= d.w; };
@@ -500,27 +564,23 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
     while (ix1 < nx && interior_x(ix1)) ++ix1;
     while (iy1 < ny && interior_y(iy1)) ++iy1;
     const bool has_interior = ix1 > ix0 && iy1 > iy0;
-    const size_t lds4 = (size_t)3 * (F_TH + 8) * F_TW * sizeof(int), lds2 = (size_t)3 * (F_TH + 4) * F_TW * sizeof(int);
+    const size_t lds4 = (size_t)3 * (F_TH + 8) * F_LP * sizeof(int), lds2 = (size_t)3 * (F_TH + 4) * F_LP * sizeof(int);
     dim3 block(F_THREADS);
-    auto run = [&](bool edge, unsigned bx0, unsigned by0, unsigned cx, unsigned cy) {
-        if (cx == 0 || cy == 0) return;
-        dim3 grid(cx, cy, d.pf);
-        if (ls.n == 4) {
-            if (edge) { set_dyn_lds(fwd_xy_kernel<4, true>, lds4); hipLaunchKernelGGL((fwd_xy_kernel<4, true>), grid, block, lds4, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
-            else { set_dyn_lds(fwd_xy_kernel<4, false>, lds4); hipLaunchKernelGGL((fwd_xy_kernel<4, false>), grid, block, lds4, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
-        } else {
-            if (edge) { set_dyn_lds(fwd_xy_kernel<2, true>, lds2); hipLaunchKernelGGL((fwd_xy_kernel<2, true>), grid, block, lds2, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
-            else { set_dyn_lds(fwd_xy_kernel<2, false>, lds2); hipLaunchKernelGGL((fwd_xy_kernel<2, false>), grid, block, lds2, st, d_rgb, mid, d, cf, aligned, (int)bx0, (int)by0); }
-        }
-    };
-    if (has_interior) {
-        run(false, ix0, iy0, ix1 - ix0, iy1 - iy0);
-        run(true, 0, 0, nx, iy0);                       // top strip
-        run(true, 0, iy1, nx, ny - iy1);                // bottom strip
-        run(true, 0, iy0, ix0, iy1 - iy0);              // left strip
-        run(true, ix1, iy0, nx - ix1, iy1 - iy0);       // right strip
+    TileMap tm{(int)nx, (int)ny, 0, 0, 0, 0};
+    if (has_interior) { tm.ix0 = (int)ix0; tm.ix1 = (int)ix1; tm.iy0 = (int)iy0; tm.iy1 = (int)iy1; }
+    else { tm.iy0 = (int)ny; tm.iy1 = (int)ny; }  // everything is "top strip"
+    const unsigned n_interior_x = has_interior ? ix1 - ix0 : 0, n_interior_y = has_interior ? iy1 - iy0 : 0;
+    const unsigned n_edge = nx * ny - n_interior_x * n_interior_y;
+    if (ls.n == 4) {
+        static const bool ok = set_dyn_lds(fwd_xy_kernel<4, true>, lds4) && set_dyn_lds(fwd_xy_kernel<4, false>, lds4);
+        (void)ok;
+        if (has_interior) hipLaunchKernelGGL((fwd_xy_kernel<4, false>), dim3(xcd_grid((unsigned long long)n_interior_x * n_interior_y * d.pf)), block, lds4, st, d_rgb, mid, d, cf, aligned, tm);
+        if (n_edge) hipLaunchKernelGGL((fwd_xy_kernel<4, true>), dim3(xcd_grid((unsigned long long)n_edge * d.pf)), block, lds4, st, d_rgb, mid, d, cf, aligned, tm);
     } else {
-        run(true, 0, 0, nx, ny);
+        static const bool ok = set_dyn_lds(fwd_xy_kernel<2, true>, lds2) && set_dyn_lds(fwd_xy_kernel<2, false>, lds2);
+        (void)ok;
+        if (has_interior) hipLaunchKernelGGL((fwd_xy_kernel<2, false>), dim3(xcd_grid((unsigned long long)n_interior_x * n_interior_y * d.pf)), block, lds2, st, d_rgb, mid, d, cf, aligned, tm);
+        if (n_edge) hipLaunchKernelGGL((fwd_xy_kernel<2, true>), dim3(xcd_grid((unsigned long long)n_edge * d.pf)), block, lds2, st, d_rgb, mid, d, cf, aligned, tm);
     }
     const size_t plane = (size_t)d.pw * d.ph;
     const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
@@ -538,21 +598,24 @@ static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkD
     hipLaunchKernelGGL((inv_t_kernel<NS, EXACT, MidT>), gt, dim3(256), 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
     const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + I_TH - 1) / I_TH;
     const int aligned = (d.w % 4 == 0) && ((((uintptr_t)rgb) & 3u) == 0u);
-    dim3 grid(nx, ny, d.f);
+    dim3 grid(xcd_grid((unsigned long long)nx * ny * d.f));
     // the inverse tiles are few enough per frame that one EDGE=true instance serves all of them
     hipLaunchKernelGGL((inv_xy_kernel<NS, true, EXACT, MidT>), grid, dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned);
 }
 
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
-                              bool exact, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
+                              bool exact, bool mid16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
-    if ((d.h + I_TH - 1) / I_TH > 65535u || d.f > 65535u) return false;
+    if ((unsigned long long)((d.w + I_TW - 1) / I_TW) * ((d.h + I_TH - 1) / I_TH) * d.f > 0x7FFFFFF0ull) return false;
+    // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too)
     if (ls.n == 4) {
         if (exact) inv_launch<4, true, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        else if (mid16) inv_launch<4, false, int16_t>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
         else inv_launch<4, false, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
     } else {
         if (exact) inv_launch<2, true, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        else if (mid16) inv_launch<2, false, int16_t>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
         else inv_launch<2, false, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
     }
     return true;
