@@ -321,7 +321,7 @@ int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks, uint64_t 
 }
 
 uint64_t default_cap(const ChunkDims& d) { return round_up(d.padded + d.padded / 4 + 4096, 256); }
-uint64_t worst_cap(const ChunkDims& d) { return round_up(2 * d.padded + 4 + 64, 256); }
+uint64_t worst_cap(const ChunkDims& d) { return round_up(2 * d.padded + 4 + 64 + 64, 256); }  // +64: dummy-store guard band
 
 // Exact reference arithmetic on caller-shaped data for chunks of more than 64 padded frames.
 int forward_generic(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step, EncodeWork& w,
@@ -397,6 +397,11 @@ int encode_collect(EncodeWork& w, hipStream_t st, std::vector<RansResult>& res) 
             return fail(kReferenceDiverges, "a symbol whose table frequency wrapped to 0 is present: the reference encoder does not terminate on this input");
         if (r.flags & kRansInternal) return fail(kInternal, "rANS kernel invariant violated");
     }
+    if (getenv("ALICE_CODEC_DEBUG"))
+        for (size_t i = 0; i < res.size(); ++i)
+            fprintf(stderr, "[alice] encode chain %zu: %llu bytes, %.1f Mcycles, %.1f ms of 100 MHz ticks => %.2f GHz\n", i, res[i].len,
+                    res[i].fast_tiles * 1024.0 / 1e6, res[i].slow_tiles * 1024.0 / 1e5,
+                    res[i].slow_tiles ? (res[i].fast_tiles / (double)res[i].slow_tiles) * 0.1 : 0.0);
     for (auto& r : res)
         if (r.flags & kRansOverflow) return -1;  // caller retries with the worst-case capacity
     return kOk;
@@ -1017,7 +1022,7 @@ uint8_t* alice_codec_rans_encode(const uint8_t* symbols, uint64_t n, const uint1
     if ((!symbols && n) || !cum_freq || !freq || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
     hipStream_t st;
     if (get_stream(&st)) return nullptr;
-    const uint64_t cap = round_up(2 * n + 4 + 64, 256);
+    const uint64_t cap = round_up(2 * n + 4 + 64 + 64, 256);
     DevBuf ds, dc, df, dt, dout, dres;
     if (ds.alloc(n) || dc.alloc(512) || df.alloc(512) || dt.alloc(sizeof(RansTable)) || dout.alloc(cap) || dres.alloc(sizeof(RansResult))) return nullptr;
     RansResult res{};

@@ -152,7 +152,7 @@ constexpr int kEncTile = 1024;  // symbols staged per global load (16 B per lane
 // without its own cum bias) its symbol.
 __device__ __forceinline__ void ripple64(uint32_t& xin, uint32_t& xout, uint32_t xmax, uint32_t xmax8,
                                          uint32_t rcp, uint32_t rsh, int32_t g, uint32_t cprev) {
-    uint32_t k, y, q, cnt;
+    uint32_t k, y, q;
     unsigned long long m1;
     // Wait states (gfx940-family): VALU-written SGPR/VCC -> VALU read needs 2 states
     // (the second compare and one SALU/nop sit between); VALU-written VGPR -> DPP read
@@ -168,20 +168,18 @@ __device__ __forceinline__ void ripple64(uint32_t& xin, uint32_t& xout, uint32_t
     "v_mul_hi_u32 %[q], %[y], %[rcp]\n\t"                                          \
     "v_lshrrev_b32_e32 %[q], %[rsh], %[q]\n\t"                                     \
     "v_mad_i32_i24 %[xout], %[q], %[g], %[y]\n\t" TAIL
+    // fully unrolled: a taken loop branch costs ~25 cycles on a lone wave (scripts/probes/latency_probe.hip)
+#define ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP("s_nop 1\n\t") ALICE_RIPPLE_STEP("s_nop 1\n\t") ALICE_RIPPLE_STEP("s_nop 1\n\t") ALICE_RIPPLE_STEP("s_nop 1\n\t")
+#define ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP4
     asm volatile(
-        "s_mov_b32 %[cnt], 16\n\t"
         "s_nop 1\n\t"
-        "1:\n\t"
-        ALICE_RIPPLE_STEP("s_nop 1\n\t")
-        ALICE_RIPPLE_STEP("s_nop 1\n\t")
-        ALICE_RIPPLE_STEP("s_nop 1\n\t")
-        ALICE_RIPPLE_STEP("s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 0\n\ts_cbranch_scc1 1b\n\t")
-        "s_nop 1\n\t"
-        : [xin] "+v"(xin), [xout] "+v"(xout), [k] "=&v"(k), [y] "=&v"(y), [q] "=&v"(q),
-          [cnt] "=&s"(cnt), [m1] "=&s"(m1)
+        ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP16
+        : [xin] "+v"(xin), [xout] "+v"(xout), [k] "=&v"(k), [y] "=&v"(y), [q] "=&v"(q), [m1] "=&s"(m1)
         : [xmax] "v"(xmax), [xmax8] "v"(xmax8), [rcp] "v"(rcp), [rsh] "v"(rsh), [g] "v"(g),
           [cprev] "v"(cprev)
-        : "vcc", "scc");
+        : "vcc");
+#undef ALICE_RIPPLE_STEP16
+#undef ALICE_RIPPLE_STEP4
 #undef ALICE_RIPPLE_STEP
 }
 
@@ -200,7 +198,11 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     const int lane = threadIdx.x;
     const uint8_t* __restrict__ sym = sym_base + (size_t)chain * sym_stride;
     const RansTable* __restrict__ tbl = tables + chain;
-    uint8_t* const out_end = out_base + (size_t)chain * cap + cap;
+    uint8_t* const region = out_base + (size_t)chain * cap;
+    uint8_t* const out_end = region + cap;
+    // lanes that have nothing to emit store to a private byte at the unused front of the region instead
+    // of branching around the store; the capacity test keeps real bytes 64 bytes away from it
+    uint8_t* const dummy = region + lane;
 
     for (int s = lane; s < 256; s += 64) {
         const RansEncEntry e = tbl->enc[s];
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     }
 
     uint32_t x = kRansL;  // RansEncoder::new, src/rans.rs:249-254
+    const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
     unsigned long long written = 0ull;
     uint32_t flags = 0u;
 
@@ -221,15 +224,18 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         const long long lo = hi - kEncTile + 16ll * lane;  // first index of this lane's 16 bytes
         if (lo >= 0) {
             const uint8_t* p = sym + lo;
-            if ((((uintptr_t)p) & 3u) == 0u) {
-                const uint32_t* p4 = (const uint32_t*)p;
+            const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+            const uint32_t* p4 = (const uint32_t*)(p - mis);   // stays inside the allocation: lo >= 0
+            if (mis == 0u) {
                 v = make_uint4(p4[0], p4[1], p4[2], p4[3]);
+            } else if (lo + 20 <= (long long)n || mis == 0u) {
+                const uint32_t t0 = p4[0], t1 = p4[1], t2 = p4[2], t3 = p4[3], t4 = p4[4];
+                const uint32_t sh = mis * 8u;
+                v = make_uint4((t0 >> sh) | (t1 << (32u - sh)), (t1 >> sh) | (t2 << (32u - sh)),
+                               (t2 >> sh) | (t3 << (32u - sh)), (t3 >> sh) | (t4 << (32u - sh)));
             } else {
-                uint32_t w[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    w[d] = (uint32_t)p[4 * d] | ((uint32_t)p[4 * d + 1] << 8) | ((uint32_t)p[4 * d + 2] << 16) |
-                           ((uint32_t)p[4 * d + 3] << 24);
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (int b = 0; b < 16; ++b) w[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
         } else {
@@ -243,6 +249,10 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         return v;
     };
 
+    struct BlockParams { uint4 ea, eb; };
+    auto sym_of = [&](int b) -> uint32_t { return tile[(kEncTile - 1 - (b * 64 + lane)) & (kEncTile - 1)]; };
+    auto params_of = [&](uint32_t s) -> BlockParams { BlockParams p; p.ea = tab_a[s]; p.eb = tab_b[s]; return p; };
+
     uint4 cur = load_tile(0);
     for (unsigned long long j = 0; j < ntiles; ++j) {
         __syncthreads();
@@ -251,14 +261,19 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         cur = load_tile(j + 1);  // in flight while this tile's 16 blocks ripple
         const long long hi = (long long)(n - j * kEncTile);
         const int valid = hi >= kEncTile ? kEncTile : (int)hi;  // tile-local indices [1024-valid, 1024)
+        const int nblocks = (valid + 63) / 64;
 
-        for (int b = 0; b < kEncTile / 64; ++b) {
-            const int local = kEncTile - 1 - (b * 64 + lane);  // descending symbol order
-            const bool active = local >= kEncTile - valid;
-            if (__ballot(active) == 0ull) break;
-            const uint32_t s = tile[local];
-            uint4 ea = tab_a[s];
-            uint4 eb = tab_b[s];
+        // Three-stage pipeline over the blocks of a tile: while block b ripples (the asm statement touches
+        // no memory), the table rows of block b+1 and the symbols of block b+2 are in flight from LDS.
+        uint32_t sym1 = sym_of(1);
+        BlockParams nxt = params_of(sym_of(0));
+        for (int b = 0; b < nblocks; ++b) {
+            const BlockParams curp = nxt;
+            nxt = params_of(sym1);
+            sym1 = sym_of(b + 2);
+            const bool active = (kEncTile - 1 - (b * 64 + lane)) >= kEncTile - valid;  // all lanes except in the last tile
+            uint4 ea = curp.ea;
+            uint4 eb = curp.eb;
             if (!active) {  // identity step
                 ea = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
                 eb = make_uint4(0u, 0u, 1u, 0u);
@@ -266,10 +281,10 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
             const uint32_t xmax = ea.x, xmax8 = ea.y, rcp = ea.z, rsh = ea.w;
             const int32_t g = (int32_t)eb.x;
             const uint32_t cbias = eb.y, freq = eb.z, cum = eb.w;
-            const bool bad = active && (freq == 0u || freq > kProbScale);
+            const bool bad = (freq - 1u) >= kProbScale;  // freq == 0 or freq > 4096 (identity lanes carry freq 1)
 
             uint32_t xin = x, xout = 0u;
-            if (__ballot(bad) == 0ull) {
+            if (__builtin_expect(__ballot(bad) == 0ull, 1)) {
                 uint32_t cprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cbias, 0x138, 0xf, 0xf, true);
                 ripple64(xin, xout, xmax, xmax8, rcp, rsh, g, cprev);
                 x = (uint32_t)__builtin_amdgcn_readlane((int)xout, 63) +
@@ -293,26 +308,27 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                 x = xs;
             }
 
-            // byte emission: lane i pushes the low k_i bytes of its pre-renormalisation state
-            const bool c1 = active && xin >= xmax;
-            const bool c2 = active && xin >= xmax8;
+            // byte emission, branch-free: lane i pushes the low k_i bytes of its pre-renormalisation state
+            // (identity lanes have xmax = 2^32-1 and never emit)
+            const bool c1 = xin >= xmax;
+            const bool c2 = xin >= xmax8;
             const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
             const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
                                  __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
             const uint32_t total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-            if (written + total + 4ull > cap) {
-                flags |= kRansOverflow;
-            } else {
-                uint8_t* p = out_end - 1 - (written + off);
-                if (c1) p[0] = (uint8_t)(xin & 0xFFu);
-                if (c2) p[-1] = (uint8_t)((xin >> 8) & 0xFFu);
-            }
+            const bool room = written + total + 4ull + 64ull <= cap;  // uniform
+            flags |= room ? 0u : kRansOverflow;
+            uint8_t* p = out_end - 1 - (written + off);
+            uint8_t* p0 = (c1 && room) ? p : dummy;
+            uint8_t* p1 = (c2 && room) ? p - 1 : dummy;
+            *p0 = (uint8_t)(xin & 0xFFu);
+            *p1 = (uint8_t)((xin >> 8) & 0xFFu);
             written += total;
         }
     }
 
     // finish (src/rans.rs:298-308): push the 4 state bytes LSB first; the reversal is implicit
-    if (written + 4ull <= cap) {
+    if (written + 4ull + 64ull <= cap) {
         if (lane < 4) out_end[-1 - (long long)(written + lane)] = (uint8_t)((x >> (8 * lane)) & 0xFFu);
     } else {
         flags |= kRansOverflow;
@@ -322,8 +338,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         results[chain].len = written;
         results[chain].flags = flags;
         results[chain].final_state = x;
-        results[chain].fast_tiles = 0u;
-        results[chain].slow_tiles = 0u;
+        // diagnostics: shader cycles and 100 MHz ticks spent in the chain (kibi-units)
+        results[chain].fast_tiles = (uint32_t)((clock64() - clk0) >> 10);
+        results[chain].slow_tiles = (uint32_t)((wall_clock64() - rt0) >> 10);
     }
 }
 
@@ -346,152 +363,27 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
 
 constexpr int kDecBlocks = 16;                 // 64-symbol blocks per fast tile
 constexpr int kDecTile = kDecBlocks * 64;      // 1024 symbols
-constexpr int kDecWinDwords = 9 * 64;          // window VGPR bank: 9 registers x 64 lanes
-constexpr int kDecWinBytes = kDecWinDwords * 4;
+constexpr int kDecWinBytes = 9 * 64 * 4;        // stream window held in 9 VGPRs (big-endian dwords)
+constexpr int kDecWinLds = kDecWinBytes;
 
-// literal registers owned by the fast-tile asm statement (all listed as clobbers)
-//   v[64:127]  slot table        v[128:136] stream window      v137 scratch   v138 record
-//   s[60:61]   {xl : x}          s[62:63]   byte window WW     s[64:65] refill pair
-//   s66 h  s67 e  s68 f  s69 b  s70 t  s71 sh  s72 av  s73 di  s74 nblk  s75 selector  s76 row
-// Measured on MI355X (scripts/probes/latency_probe.hip): every SALU/VALU instruction of a lone wave
-// costs ~4 cycles, a v_readlane result reaches the scalar unit ~24 cycles after issue, an untaken
-// branch costs ~10 cycles and a taken one ~25.  Hence: the shift and the record sit in the readlane's
-// shadow, and the refill test runs once per two symbols (a 64-bit window holds 2 x 16 bits of slack).
-#define ALICE_DEC_CORE(LANE)                                                       \
-    "s_bfe_u32 s76, s61, 0x60006\n\t"                                              \
-    "s_set_gpr_idx_idx s76\n\t"                                                    \
-    "v_readlane_b32 s67, v64, s61\n\t"                                             \
-    "s_lshr_b32 s66, s61, 12\n\t"                                                  \
-    "v_writelane_b32 v138, s61, " #LANE "\n\t"                                     \
-    "s_and_b32 s68, s67, 0xffff\n\t"                                               \
-    "s_lshr_b32 s69, s67, 16\n\t"                                                  \
-    "s_mul_i32 s70, s68, s66\n\t"                                                  \
-    "s_add_u32 s61, s70, s69\n\t"                                                  \
-    "s_cmp_lt_u32 s61, 0x800000\n\t"                                               \
-    "s_cbranch_scc0 10" #LANE "f\n\t"                                              \
-    "s_cmp_lt_u32 s61, 0x8000\n\t"                                                 \
-    "s_cselect_b32 s71, 16, 8\n\t"                                                 \
-    "s_mov_b32 s60, s63\n\t"                                                       \
-    "s_lshl_b64 s[60:61], s[60:61], s71\n\t"                                       \
-    "s_lshl_b64 s[62:63], s[62:63], s71\n\t"                                       \
-    "s_sub_u32 s72, s72, s71\n\t"                                                  \
-    "10" #LANE ":\n\t"
+// The tile body is generated (gen/gen_rans_decode_asm.py -> rans_decode_tile.inc, which documents the
+// register plan and the measured instruction costs behind its shape); per symbol, all on the scalar side:
+//     row = x[11:6]; freq = F[row][x[5:0]]; bias = B[row][x[5:0]]      (VGPR-index mode + two v_readlane)
+//     x = freq * (x >> 12) + bias
+//     sh = shift_by_clz[clz(x)]                                         (s_flbit + s_movrels: 0, 8 or 16)
+//     {window : x} <<= sh                                               (64-bit scalar shifts)
+// and once per two symbols a test whether the 64-bit byte window needs its next dword.
+#include "rans_decode_tile.inc"
 
-#define ALICE_DEC_REFILL(LANE)                                                     \
-    "s_cmp_lt_u32 s72, 33\n\t"                                                     \
-    "s_cbranch_scc0 11" #LANE "f\n\t"                                              \
-    "s_lshr_b32 s76, s73, 6\n\t"                                                   \
-    "s_set_gpr_idx_idx s76\n\t"                                                    \
-    "v_readlane_b32 s65, v128, s73\n\t"                                            \
-    "s_mov_b32 s64, 0\n\t"                                                         \
-    "s_add_u32 s73, s73, 1\n\t"                                                    \
-    "s_lshr_b64 s[64:65], s[64:65], s72\n\t"                                       \
-    "s_or_b64 s[62:63], s[62:63], s[64:65]\n\t"                                    \
-    "s_add_u32 s72, s72, 32\n\t"                                                   \
-    "11" #LANE ":\n\t"
-
-#define ALICE_DEC_SYM2(A, B) ALICE_DEC_CORE(A) ALICE_DEC_CORE(B) ALICE_DEC_REFILL(B)
-#define ALICE_DEC_SYM4(A, B, C_, D) ALICE_DEC_SYM2(A, B) ALICE_DEC_SYM2(C_, D)
-
-#define ALICE_DS_ROW(R, BASE, ADDR) "ds_read_b32 v" #R ", " ADDR " offset:" #BASE "\n\t"
-
-// Decodes nblk*64 symbols on the fast path.  tab_addr / win_addr / rec_addr are this lane's LDS
-// byte addresses (base + 4*lane).  pos = byte offset of the next stream byte inside the window.
+// Decodes nblk*64 symbols on the fast path.  tab_addr / win_addr / rec_addr are this lane's LDS byte
+// addresses (base + 4*lane).  pos = byte offset of the next stream byte inside the window.
 __device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, uint32_t tab_addr, uint32_t win_addr,
                                               uint32_t rec_addr, uint32_t nblk) {
     uint32_t xo, po;
-    asm volatile(
-        // ---- slot table -> v[64:127] ----
-        "ds_read_b32 v64, %[ta] offset:0\n\t"     "ds_read_b32 v65, %[ta] offset:256\n\t"
-        "ds_read_b32 v66, %[ta] offset:512\n\t"   "ds_read_b32 v67, %[ta] offset:768\n\t"
-        "ds_read_b32 v68, %[ta] offset:1024\n\t"  "ds_read_b32 v69, %[ta] offset:1280\n\t"
-        "ds_read_b32 v70, %[ta] offset:1536\n\t"  "ds_read_b32 v71, %[ta] offset:1792\n\t"
-        "ds_read_b32 v72, %[ta] offset:2048\n\t"  "ds_read_b32 v73, %[ta] offset:2304\n\t"
-        "ds_read_b32 v74, %[ta] offset:2560\n\t"  "ds_read_b32 v75, %[ta] offset:2816\n\t"
-        "ds_read_b32 v76, %[ta] offset:3072\n\t"  "ds_read_b32 v77, %[ta] offset:3328\n\t"
-        "ds_read_b32 v78, %[ta] offset:3584\n\t"  "ds_read_b32 v79, %[ta] offset:3840\n\t"
-        "ds_read_b32 v80, %[ta] offset:4096\n\t"  "ds_read_b32 v81, %[ta] offset:4352\n\t"
-        "ds_read_b32 v82, %[ta] offset:4608\n\t"  "ds_read_b32 v83, %[ta] offset:4864\n\t"
-        "ds_read_b32 v84, %[ta] offset:5120\n\t"  "ds_read_b32 v85, %[ta] offset:5376\n\t"
-        "ds_read_b32 v86, %[ta] offset:5632\n\t"  "ds_read_b32 v87, %[ta] offset:5888\n\t"
-        "ds_read_b32 v88, %[ta] offset:6144\n\t"  "ds_read_b32 v89, %[ta] offset:6400\n\t"
-        "ds_read_b32 v90, %[ta] offset:6656\n\t"  "ds_read_b32 v91, %[ta] offset:6912\n\t"
-        "ds_read_b32 v92, %[ta] offset:7168\n\t"  "ds_read_b32 v93, %[ta] offset:7424\n\t"
-        "ds_read_b32 v94, %[ta] offset:7680\n\t"  "ds_read_b32 v95, %[ta] offset:7936\n\t"
-        "ds_read_b32 v96, %[ta] offset:8192\n\t"  "ds_read_b32 v97, %[ta] offset:8448\n\t"
-        "ds_read_b32 v98, %[ta] offset:8704\n\t"  "ds_read_b32 v99, %[ta] offset:8960\n\t"
-        "ds_read_b32 v100, %[ta] offset:9216\n\t" "ds_read_b32 v101, %[ta] offset:9472\n\t"
-        "ds_read_b32 v102, %[ta] offset:9728\n\t" "ds_read_b32 v103, %[ta] offset:9984\n\t"
-        "ds_read_b32 v104, %[ta] offset:10240\n\t" "ds_read_b32 v105, %[ta] offset:10496\n\t"
-        "ds_read_b32 v106, %[ta] offset:10752\n\t" "ds_read_b32 v107, %[ta] offset:11008\n\t"
-        "ds_read_b32 v108, %[ta] offset:11264\n\t" "ds_read_b32 v109, %[ta] offset:11520\n\t"
-        "ds_read_b32 v110, %[ta] offset:11776\n\t" "ds_read_b32 v111, %[ta] offset:12032\n\t"
-        "ds_read_b32 v112, %[ta] offset:12288\n\t" "ds_read_b32 v113, %[ta] offset:12544\n\t"
-        "ds_read_b32 v114, %[ta] offset:12800\n\t" "ds_read_b32 v115, %[ta] offset:13056\n\t"
-        "ds_read_b32 v116, %[ta] offset:13312\n\t" "ds_read_b32 v117, %[ta] offset:13568\n\t"
-        "ds_read_b32 v118, %[ta] offset:13824\n\t" "ds_read_b32 v119, %[ta] offset:14080\n\t"
-        "ds_read_b32 v120, %[ta] offset:14336\n\t" "ds_read_b32 v121, %[ta] offset:14592\n\t"
-        "ds_read_b32 v122, %[ta] offset:14848\n\t" "ds_read_b32 v123, %[ta] offset:15104\n\t"
-        "ds_read_b32 v124, %[ta] offset:15360\n\t" "ds_read_b32 v125, %[ta] offset:15616\n\t"
-        "ds_read_b32 v126, %[ta] offset:15872\n\t" "ds_read_b32 v127, %[ta] offset:16128\n\t"
-        // ---- stream window -> v[128:136], bytes swapped to big-endian ----
-        "ds_read_b32 v128, %[wa] offset:0\n\t"    "ds_read_b32 v129, %[wa] offset:256\n\t"
-        "ds_read_b32 v130, %[wa] offset:512\n\t"  "ds_read_b32 v131, %[wa] offset:768\n\t"
-        "ds_read_b32 v132, %[wa] offset:1024\n\t" "ds_read_b32 v133, %[wa] offset:1280\n\t"
-        "ds_read_b32 v134, %[wa] offset:1536\n\t" "ds_read_b32 v135, %[wa] offset:1792\n\t"
-        "ds_read_b32 v136, %[wa] offset:2048\n\t"
-        "s_mov_b32 s75, 0x00010203\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_perm_b32 v128, v128, v128, s75\n\t" "v_perm_b32 v129, v129, v129, s75\n\t"
-        "v_perm_b32 v130, v130, v130, s75\n\t" "v_perm_b32 v131, v131, v131, s75\n\t"
-        "v_perm_b32 v132, v132, v132, s75\n\t" "v_perm_b32 v133, v133, v133, s75\n\t"
-        "v_perm_b32 v134, v134, v134, s75\n\t" "v_perm_b32 v135, v135, v135, s75\n\t"
-        "v_perm_b32 v136, v136, v136, s75\n\t"
-        // ---- scalar state: x, 64-bit byte window primed with two dwords ----
-        "s_mov_b32 s61, %[xi]\n\t"
-        "s_mov_b32 s74, %[nb]\n\t"
-        "s_lshr_b32 s73, %[pi], 2\n\t"            // di = pos / 4
-        "s_and_b32 s71, %[pi], 3\n\t"
-        "s_lshl_b32 s71, s71, 3\n\t"              // bits to drop from the first dword
-        "s_lshr_b32 s76, s73, 6\n\t"
-        "s_set_gpr_idx_on s76, 0x1\n\t"          // VGPR-index mode, src0 relative, stays on for the whole tile
-        "s_nop 1\n\t"
-        "v_readlane_b32 s63, v128, s73\n\t"
-        "s_add_u32 s73, s73, 1\n\t"
-        "s_lshr_b32 s76, s73, 6\n\t"
-        "s_set_gpr_idx_idx s76\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 s62, v128, s73\n\t"
-        "s_add_u32 s73, s73, 1\n\t"
-        "s_lshl_b64 s[62:63], s[62:63], s71\n\t"
-        "s_sub_u32 s72, 64, s71\n\t"              // valid bits in the window
-        "2:\n\t"
-        ALICE_DEC_SYM4(0, 1, 2, 3) ALICE_DEC_SYM4(4, 5, 6, 7) ALICE_DEC_SYM4(8, 9, 10, 11) ALICE_DEC_SYM4(12, 13, 14, 15)
-        ALICE_DEC_SYM4(16, 17, 18, 19) ALICE_DEC_SYM4(20, 21, 22, 23) ALICE_DEC_SYM4(24, 25, 26, 27) ALICE_DEC_SYM4(28, 29, 30, 31)
-        ALICE_DEC_SYM4(32, 33, 34, 35) ALICE_DEC_SYM4(36, 37, 38, 39) ALICE_DEC_SYM4(40, 41, 42, 43) ALICE_DEC_SYM4(44, 45, 46, 47)
-        ALICE_DEC_SYM4(48, 49, 50, 51) ALICE_DEC_SYM4(52, 53, 54, 55) ALICE_DEC_SYM4(56, 57, 58, 59) ALICE_DEC_SYM4(60, 61, 62, 63)
-        "ds_write_b32 %[ra], v138\n\t"
-        "v_add_u32_e32 %[ra], 0x100, %[ra]\n\t"
-        "s_sub_u32 s74, s74, 1\n\t"
-        "s_cmp_lg_u32 s74, 0\n\t"
-        "s_cbranch_scc1 2b\n\t"
-        "s_set_gpr_idx_off\n\t"
-        // ---- results: state, consumed position = 4*di - valid_bits/8 ----
-        "s_lshl_b32 s70, s73, 2\n\t"
-        "s_lshr_b32 s71, s72, 3\n\t"
-        "s_sub_u32 %[po], s70, s71\n\t"
-        "s_mov_b32 %[xo], s61\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        : [xo] "=&s"(xo), [po] "=&s"(po), [ra] "+v"(rec_addr)
-        : [xi] "s"(x), [pi] "s"(pos), [nb] "s"(nblk), [ta] "v"(tab_addr), [wa] "v"(win_addr)
-        : "memory", "scc", "m0",
-          "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76",
-          "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-          "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
-          "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
-          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
-          "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137",
-          "v138");
+    asm volatile(ALICE_DEC_TILE_ASM
+                 : [xo] "=&s"(xo), [po] "=&s"(po), [ra] "+v"(rec_addr)
+                 : [xi] "s"(x), [pi] "s"(pos), [nb] "s"(nblk), [ta] "v"(tab_addr), [wa] "v"(win_addr)
+                 : ALICE_DEC_TILE_CLOBBERS);
     x = xo;
     pos = po;
 }
@@ -500,7 +392,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
                                                          RansResult* __restrict__ results) {
     __shared__ uint32_t slot_tab[kProbScale];                         // freq | (slot - cum) << 16
     __shared__ uint8_t c2s[kProbScale];                               // cum_to_sym
-    __shared__ __attribute__((aligned(16))) uint8_t win[kDecWinBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t win[kDecWinLds];
     __shared__ uint32_t rec[kDecTile];                                // pre-update states of a fast tile
     __shared__ __attribute__((aligned(16))) uint8_t obuf[kDecTile];
 
@@ -548,7 +440,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         // stage the stream window [wbase, wbase + 2304) (zero beyond len)
         const unsigned long long wbase = pos & ~3ull;
         __syncthreads();
-        for (int i = lane * 4; i < kDecWinBytes; i += 64 * 4) {
+        for (int i = lane * 4; i < kDecWinLds; i += 64 * 4) {
             const unsigned long long o = wbase + (unsigned long long)i;
             uint32_t w = 0u;
             if (o + 4ull <= len && ((((uintptr_t)(d.in + o)) & 3u) == 0u)) {
@@ -564,7 +456,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         // the owed renormalisation first (src/rans.rs:365-368); it needs at most a few window bytes
         // unless the state is 0, which the exact loop below handles byte by byte
         uint32_t got = 0u;
-        bool fast = (want == (uint32_t)kDecTile) && (len - wbase >= (unsigned long long)kDecWinBytes);
+        bool fast = (want == (uint32_t)kDecTile) && (len - wbase >= (unsigned long long)kDecWinLds);
         if (fast && pending) {
             uint32_t xs = x;
             unsigned long long ps = pos;
