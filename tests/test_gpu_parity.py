@@ -251,42 +251,36 @@ def test_rans_streams(gpu_codec, oracle_mod):
     sym = rng.choice([3, 3, 3, 7, 255], 5000).astype(np.uint8)
     e = gpu_codec.RansEncoder(); e.encode_symbols(sym, tg)
     assert e.finish() == oracle_mod.rans_encode(sym, to)
-    # a symbol whose frequency wrapped to exactly 0: the reference never terminates; we report it
-    hist = np.zeros(256, np.uint32); hist[0] = 4095 * 16; hist[254] = 16  # sum of freqs = 4095 + 254 ... -> craft below
-    fr = oracle_mod.FrequencyTable(hist).freq
-    if int(fr[255]) == 0:
-        e = gpu_codec.RansEncoder(); e.encode_symbols([255, 0], gpu_codec.FrequencyTable.from_histogram(hist))
-        with pytest.raises(gpu_codec.CodecError) as err:
-            e.finish()
-        assert err.value.kind == "ReferenceDiverges"
     # decoder on short / empty / garbage input (state 0, pos < len guard: src/rans.rs:341-347, 365-368)
     for data in (b"", b"\x01", b"\x01\x02\x03", bytes(rng.integers(0, 256, 50, dtype=np.uint8)), bytes(200)):
         assert np.array_equal(gpu_codec.RansDecoder(data).decode_n(300, uni_g), oracle_mod.rans_decode(data, 300, uni_o))
 
 
 def test_zero_frequency_symbol_is_reported(gpu_codec, oracle_mod):
-    """Crafted table with freq[255] == 0 (running sum of the others == 4096 + freq_255)."""
+    """A histogram whose table gives symbol 255 frequency 0: counts 3842 / 254 out of 4096 normalise to
+    themselves, the 254 unused symbols take one slot each, so the sum is 4096 + 254 and the "fix" on the
+    last symbol (src/rans.rs:128-132) subtracts exactly its own frequency.  The reference encoder then never
+    terminates on a 255 (x_max = 0, src/rans.rs:275-279); both the oracle and the GPU path report it."""
     hist = np.zeros(256, np.uint32)
-    hist[0] = 3842 * 1000; hist[255] = 1000   # freq0 = 3841 (floor), 254 unused -> +254, freq255 = 1 -> total 4096: adjust
-    # search a histogram whose table has freq[255] == 0
-    found = None
-    for a in range(3800, 3900):
-        hist[0] = a; hist[255] = 1
-        hist[1] = 4096 - a - 1 if 4096 - a - 1 > 0 else 0
-        fr = oracle_mod.FrequencyTable(hist).freq
-        if int(fr[255]) == 0:
-            found = hist.copy(); break
-    if found is None:
-        pytest.skip("no zero-frequency table found in the searched family")
-    tg = gpu_codec.FrequencyTable.from_histogram(found)
-    assert int(tg.freq[255]) == 0
+    hist[0] = 3842
+    hist[255] = 254
+    ot = oracle_mod.FrequencyTable(hist)
+    assert int(ot.freq[255]) == 0 and int(ot.freq[0]) == 3842
+    tg = gpu_codec.FrequencyTable.from_histogram(hist)
+    assert np.array_equal(tg.freq, ot.freq) and np.array_equal(tg.cum_freq, ot.cum_freq)
+    # data without the poisoned symbol still encodes, identically
+    sym = np.zeros(1000, np.uint8)
+    e = gpu_codec.RansEncoder(); e.encode_symbols(sym, tg)
+    assert e.finish() == oracle_mod.rans_encode(sym, ot)
     e = gpu_codec.RansEncoder(); e.encode_symbols([0, 255, 0], tg)
     with pytest.raises(gpu_codec.CodecError) as err:
         e.finish()
     assert err.value.kind == "ReferenceDiverges"
     with pytest.raises(oracle_mod.OracleError) as oerr:
-        oracle_mod.rans_encode([0, 255, 0], oracle_mod.FrequencyTable(found))
+        oracle_mod.rans_encode([0, 255, 0], ot)
     assert oerr.value.code == oracle_mod.ERR_REFERENCE_DIVERGES
+    # the full pipeline on a chunk whose Y channel produces exactly that histogram is not constructible from
+    # RGB input in general; the stage-level check above is the coverage for this divergence
 
 
 def test_psnr_ffi(gpu_codec, oracle_mod):  # src/ffi.rs:448-464
