@@ -411,12 +411,18 @@ struct DecodeWork {
     ChunkDims d{};
     int n_chunks = 0;
     DevBuf mid, tmp, sym, hist, tables, descs, results, planes, vol;
+    uint8_t* sym_ptr = nullptr;   // decoded symbols: own buffer, or one lent by the caller
+    int32_t* mid_ptr = nullptr;
 };
 
-int decode_work_alloc(DecodeWork& w, const ChunkDims& d, int n_chunks) {
+// sym_ext / mid_ext: buffers the caller lends (a batch reuses its encode-side symbol and scratch buffers,
+// which are dead once the encode has finished)
+int decode_work_alloc(DecodeWork& w, const ChunkDims& d, int n_chunks, uint8_t* sym_ext = nullptr, int32_t* mid_ext = nullptr) {
     w.d = d; w.n_chunks = n_chunks;
-    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
-    TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
+    if (mid_ext) w.mid_ptr = mid_ext;
+    else { TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t))); w.mid_ptr = w.mid.as<int32_t>(); }
+    if (sym_ext) w.sym_ptr = sym_ext;
+    else { TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded)); w.sym_ptr = w.sym.as<uint8_t>(); }
     TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
     TRY(w.tables.alloc((size_t)n_chunks * 3 * sizeof(RansTable)));
     TRY(w.descs.alloc((size_t)n_chunks * 3 * sizeof(RansDecodeDesc)));
@@ -429,7 +435,7 @@ int inverse_generic(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const
     if (!w.planes.p) TRY(w.planes.alloc(3 * d.n_pixels * sizeof(int16_t)));
     if (!w.tmp.p) TRY(w.tmp.alloc(d.padded * sizeof(int32_t)));
     int16_t* pl = w.planes.as<int16_t>();
-    int32_t* qb = w.mid.as<int32_t>();
+    int32_t* qb = w.mid_ptr;
     int32_t* vol = qb + d.padded;
     const uint64_t W = d.pw, H = d.ph, D = d.pf;
     for (int c = 0; c < 3; ++c) {
@@ -459,7 +465,7 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
             RansDecodeDesc& ds = descs[(size_t)b * 3 + c];
             ds.in = d_payload[b] + off;
             ds.in_len = h.compressed_len;
-            ds.out = w.sym.as<uint8_t>() + ((size_t)b * 3 + c) * d.padded;
+            ds.out = w.sym_ptr + ((size_t)b * 3 + c) * d.padded;
             ds.n = d.padded;
             ds.table = w.tables.as<RansTable>() + ((size_t)b * 3 + c);
             off += h.compressed_len;
@@ -475,9 +481,9 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
     for (int b = 0; b < B; ++b) {
         int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
         const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
-        const uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
+        const uint8_t* sym = w.sym_ptr + (size_t)b * 3 * d.padded;
         uint8_t* rgb = d_rgb_out + (size_t)b * d.n_pixels * 3;
-        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, w.mid.as<int32_t>(), rgb, st))
+        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, w.mid_ptr, rgb, st))
             TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, rgb, st));
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[7], st));
@@ -886,7 +892,10 @@ int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stri
     hipStream_t st = (hipStream_t)hip_stream;
     b->dec_stream = st;
     b->dec_timed = false;
-    if (!b->dec_ready) { TRY(decode_work_alloc(b->dec, b->d, (int)b->n_chunks)); b->dec_ready = true; }
+    if (!b->dec_ready) {
+        TRY(decode_work_alloc(b->dec, b->d, (int)b->n_chunks, b->enc.sym.as<uint8_t>(), b->enc.mid.as<int32_t>()));
+        b->dec_ready = true;
+    }
     // headers: one strided device-to-host copy, then validation on the host
     std::vector<uint8_t> hdr((size_t)b->n_chunks * kAlcHeaderBytes);
     HIP_TRY(hipMemcpy2DAsync(hdr.data(), kAlcHeaderBytes, d_alc, alc_stride, kAlcHeaderBytes, b->n_chunks, hipMemcpyDeviceToHost, st));
