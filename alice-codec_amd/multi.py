@@ -17,8 +17,27 @@ def shard_chunks(n_chunks_total: int, rank: int, world: int) -> List[int]:
     return [k for k in range(n_chunks_total) if k % world == rank]
 
 
+class PendingGather:
+    """Handle of a gather started with gather_alc_start(): wait() returns what gather_alc() returns."""
+
+    def __init__(self, reqs, result):
+        self._reqs, self._result = reqs, result
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+        self._reqs = []
+        return self._result
+
+
 def gather_alc(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
                group: Optional[dist.ProcessGroup] = None) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+    """Blocking form of gather_alc_start()."""
+    return gather_alc_start(packed, sizes, dst, group).wait()
+
+
+def gather_alc_start(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
+                     group: Optional[dist.ProcessGroup] = None, blob: Optional[torch.Tensor] = None) -> PendingGather:
     """Variable-length gather of per-rank `.alc` blobs.
 
     packed: uint8 tensor holding this rank's chunks back to back (only the first sizes.sum() bytes count).
@@ -26,7 +45,8 @@ def gather_alc(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
     Returns on rank `dst`: (blob, all_sizes) with blob = rank 0's bytes, rank 1's bytes, ... and
     all_sizes of shape [world, chunks_per_rank]; None elsewhere.
     One small all_gather (lengths) plus one point-to-point transfer per peer: a fan-in on the
-    root's links, no ring."""
+    root's links, no ring.  The transfers are left in flight (RCCL runs them on its own stream) so the
+    caller can overlap them with the decode; `blob` lets the root reuse its receive buffer across steps."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     sizes = sizes.to(packed.device, torch.int64)
@@ -36,7 +56,10 @@ def gather_alc(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
     totals = all_sizes_t.sum(dim=1).tolist()
     mine = int(totals[rank])
     if rank == dst:
-        blob = torch.empty(int(sum(totals)), dtype=torch.uint8, device=packed.device)
+        need = int(sum(totals))
+        if blob is None or blob.numel() < need:
+            blob = torch.empty(need, dtype=torch.uint8, device=packed.device)
+        blob = blob[:need]
         offs = [0]
         for t in totals:
             offs.append(offs[-1] + int(t))
@@ -45,14 +68,10 @@ def gather_alc(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
         for r in range(world):
             if r != dst and totals[r] > 0:
                 ops.append(dist.P2POp(dist.irecv, blob[offs[r]:offs[r + 1]], r, group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        return blob, all_sizes_t
-    if mine > 0:
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed[:mine].contiguous(), dst, group)]):
-            req.wait()
-    return None
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        return PendingGather(reqs, (blob, all_sizes_t))
+    reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, packed[:mine], dst, group)]) if mine > 0 else []
+    return PendingGather(reqs, None)
 
 
 def split_blob(blob: torch.Tensor, all_sizes: torch.Tensor) -> List[bytes]:

@@ -31,6 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner) write to
+# file descriptor 1 directly, so keep a private copy of stdout for the result and point fd 1 at stderr.
+_RESULT_OUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -108,9 +113,13 @@ def main() -> None:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ac.set_device(local)
-    if world > 1:
+    # ALICE_BENCH_FORCE_DIST=1 exercises the distributed code path with a single rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("ALICE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.chunks
     px_chunk = W * H * F
@@ -121,20 +130,27 @@ def main() -> None:
     batch = ac.Batch(W, H, F, B, QUALITY, WAVELET)
     stream = torch.cuda.current_stream().cuda_stream
     packed = None
+    blob = None
     stage_acc = {}
     n_acc = 0
 
     def step(record: bool):
-        nonlocal packed, n_acc
+        nonlocal packed, blob, n_acc
         batch.encode(rgb.data_ptr(), stream)
         sizes = batch.encode_finish()
-        if world > 1:
+        pending = None
+        if use_dist:
+            # the gather of the finished .alc blobs on rank 0 runs on RCCL's stream beside the decode
             if packed is None:
                 packed = torch.empty(int(sizes.sum()) + 4096, dtype=torch.uint8, device=dev)
             batch.pack_alc(sizes, packed.data_ptr(), packed.numel(), stream)
-            multi.gather_alc(packed, torch.from_numpy(sizes.astype(np.int64)))
+            pending = multi.gather_alc_start(packed, torch.from_numpy(sizes.astype(np.int64)), blob=blob)
         batch.decode(batch.alc_ptr(0), batch.alc_stride, out.data_ptr(), stream)
         batch.decode_finish()
+        if pending is not None:
+            res = pending.wait()
+            if res is not None:
+                blob = res[0]
         if record:
             for k, v in batch.stage_ms().items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
@@ -143,7 +159,7 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -156,7 +172,7 @@ def main() -> None:
         sizes = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -216,8 +232,9 @@ def main() -> None:
             sample = rgb[0, :fr].contiguous().cpu().numpy().reshape(-1)
             chunk = ac.FrameEncoder.with_wavelet(QUALITY, WAVELET).encode(sample, W, H, fr)
             result["cpu_baseline"] = cpu_baseline(sample, fr, chunk.to_bytes(), ac.FrameDecoder().decode(chunk))
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        _RESULT_OUT.write(json.dumps(result) + "\n")
+        _RESULT_OUT.flush()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
