@@ -12,6 +12,7 @@
 // alice_codec_last_error().
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -306,21 +307,56 @@ struct EncodeWork {
     DevBuf mid, tmp, sym, hist, tables, streams, results, alc, sizes, planes;
 };
 
-int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks, uint64_t cap) {
-    w.d = d; w.n_chunks = n_chunks; w.cap = cap;
-    w.alc_stride = round_up((uint64_t)kAlcHeaderBytes + 3 * cap, 256);
+int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks) {
+    w.d = d; w.n_chunks = n_chunks; w.cap = 0; w.alc_stride = 0;
     TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
     TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
     TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
     TRY(w.tables.alloc((size_t)n_chunks * 3 * sizeof(RansTable)));
-    TRY(w.streams.alloc((size_t)n_chunks * 3 * cap + 256));  // slack: the compaction copy reads whole dwords
     TRY(w.results.alloc((size_t)n_chunks * 3 * sizeof(RansResult)));
-    TRY(w.alc.alloc((size_t)n_chunks * w.alc_stride));
     TRY(w.sizes.alloc((size_t)n_chunks * sizeof(unsigned long long)));
     return kOk;
 }
 
-uint64_t default_cap(const ChunkDims& d) { return round_up(d.padded + d.padded / 4 + 4096, 256); }
+// Stream regions and .alc buffers for a per-chain capacity (re-allocated only when it grows).
+int encode_work_set_cap(EncodeWork& w, uint64_t cap) {
+    if (cap <= w.cap && w.streams.p && w.alc.p) return kOk;
+    w.streams.reset();
+    w.alc.reset();
+    w.cap = cap;
+    w.alc_stride = round_up((uint64_t)kAlcHeaderBytes + 3 * cap, 256);
+    TRY(w.streams.alloc((size_t)w.n_chunks * 3 * cap + 256));  // slack: the compaction copy reads whole dwords
+    TRY(w.alc.alloc((size_t)w.n_chunks * w.alc_stride));
+    return kOk;
+}
+
+// Upper bound of a chain's stream length from its histogram.  The table is the reference's
+// (src/rans.rs:102-150); a symbol of frequency f costs log2(4096 / f) bits, the floor in x / f loses less
+// than log2(1 + 2^-11) bits per symbol (the state is at least f * 2^11 when it is divided), and the final
+// state adds 4 bytes.  A margin on top keeps this a capacity, not a prediction; the kernel still checks.
+uint64_t estimate_stream_cap(const uint32_t* hist, uint64_t n) {
+    unsigned long long total = 0;
+    for (int i = 0; i < 256; ++i) total += hist[i];
+    if (total == 0) return 4096;
+    long double bits = 0;
+    unsigned nt = 0;
+    unsigned freq[256];
+    for (int i = 0; i < 256; ++i) {
+        unsigned f = hist[i] == 0 ? 1u : (unsigned)std::max<unsigned long long>((unsigned long long)hist[i] * kProbScale / total, 1ull);
+        freq[i] = f;
+        nt += f;
+    }
+    if (nt != kProbScale) freq[255] = (unsigned)((int)freq[255] + ((int)kProbScale - (int)nt)) & 0xFFFFu;
+    for (int i = 0; i < 256; ++i) {
+        if (!hist[i]) continue;
+        const unsigned f = freq[i];
+        if (f == 0) return 0;                                   // reported by the kernel as a divergence
+        if (f < kProbScale) bits += (long double)hist[i] * log2l((long double)kProbScale / (long double)f);
+    }
+    const long double bytes = bits / 8.0L;
+    return (uint64_t)(bytes * 1.002L) + n / 4096 + 4096 + 64;
+}
+
 uint64_t worst_cap(const ChunkDims& d) { return round_up(2 * d.padded + 4 + 64 + 64, 256); }  // +64: dummy-store guard band
 
 // Exact reference arithmetic on caller-shaped data for chunks of more than 64 padded frames.
@@ -357,9 +393,11 @@ struct StageEvents {
     ~StageEvents() { if (ready) for (auto& e : ev) (void)hipEventDestroy(e); }
 };
 
-// Launches the whole encode of n_chunks chunks on `st`; results stay on the device.
+// Encode of n_chunks chunks on `st`; results stay on the device.  Phase A (transforms) is followed by one
+// host round trip that sizes the stream regions from the histograms (cap_override != 0 skips that and
+// forces a capacity, used by the overflow retry); phase B (tables, chains, assembly) is asynchronous.
 int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wavelet, hipStream_t st,
-                  StageEvents* evs) {
+                  StageEvents* evs, uint64_t cap_override = 0) {
     const ChunkDims& d = w.d;
     const int32_t step = quality_to_step(quality);
     const int B = w.n_chunks;
@@ -373,6 +411,15 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
             TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[1], st));
+    uint64_t cap = cap_override;
+    if (!cap) {
+        std::vector<uint32_t> hist((size_t)B * 3 * 256);
+        HIP_TRY(hipMemcpyAsync(hist.data(), w.hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int c = 0; c < 3 * B; ++c) cap = std::max(cap, estimate_stream_cap(&hist[(size_t)c * 256], d.padded));
+        cap = std::min(round_up(cap, 256), worst_cap(d));
+    }
+    TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[2], st));
     launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.streams.as<uint8_t>(),
@@ -548,14 +595,12 @@ int encode_host(const FrameEncoder& enc, const uint8_t* rgb, uint64_t rgb_len, u
     HIP_TRY(hipMemcpyAsync(d_rgb.p, rgb, rgb_len, hipMemcpyHostToDevice, st));
     EncodeWork w;
     std::vector<RansResult> res;
-    uint64_t cap = default_cap(d);
+    TRY(encode_work_alloc(w, d, 1));
     for (int attempt = 0;; ++attempt) {
-        TRY(encode_work_alloc(w, d, 1, cap));
-        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr));
+        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, attempt ? worst_cap(d) : 0));
         int rc = encode_collect(w, st, res);
         if (rc == kOk) break;
         if (rc != -1 || attempt > 0) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
-        cap = worst_cap(d);
     }
     uint64_t payload = res[0].len + res[1].len + res[2].len;
     std::vector<uint8_t> alc((size_t)kAlcHeaderBytes + payload);
@@ -663,6 +708,7 @@ struct AliceBatch {
     bool dec_ready = false;
     StageEvents evs;
     hipStream_t enc_stream = nullptr, dec_stream = nullptr;
+    const uint8_t* last_rgb = nullptr;
     bool enc_timed = false, dec_timed = false;
     float stage_ms[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -837,7 +883,7 @@ AliceBatch* alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t f
     AliceBatch* b = new (std::nothrow) AliceBatch();
     if (!b) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
     b->d = d; b->n_chunks = n_chunks; b->quality = quality; b->wavelet = wavelet_type; b->device = tl_device;
-    if (encode_work_alloc(b->enc, d, (int)n_chunks, default_cap(d)) != kOk || b->evs.init() != kOk) { delete b; return nullptr; }
+    if (encode_work_alloc(b->enc, d, (int)n_chunks) != kOk || b->evs.init() != kOk) { delete b; return nullptr; }
     return b;
 }
 void alice_codec_batch_destroy(AliceBatch* b) { delete b; }
@@ -848,6 +894,7 @@ int alice_codec_batch_encode(AliceBatch* b, const void* d_rgb, void* hip_stream)
     TRY(ensure_device());
     b->enc_stream = (hipStream_t)hip_stream;
     b->enc_timed = false;
+    b->last_rgb = (const uint8_t*)d_rgb;
     return encode_launch((const uint8_t*)d_rgb, b->enc, b->quality, b->wavelet, b->enc_stream, &b->evs);
 }
 int alice_codec_batch_encode_finish(AliceBatch* b, uint64_t* sizes) {
@@ -855,7 +902,11 @@ int alice_codec_batch_encode_finish(AliceBatch* b, uint64_t* sizes) {
     if (!b) return fail(kNullArgument, "null argument");
     std::vector<RansResult> res;
     int rc = encode_collect(b->enc, b->enc_stream, res);
-    if (rc == -1) return fail(kInternal, "rANS output exceeded the batch capacity (1.25 bytes/symbol)");
+    if (rc == -1 && b->last_rgb) {  // capacity estimate exceeded (never observed): run again with the worst case
+        TRY(encode_launch(b->last_rgb, b->enc, b->quality, b->wavelet, b->enc_stream, &b->evs, worst_cap(b->d)));
+        rc = encode_collect(b->enc, b->enc_stream, res);
+    }
+    if (rc == -1) return fail(kInternal, "rANS output exceeded the worst-case capacity");
     if (rc) return rc;
     for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&b->stage_ms[i], b->evs.ev[i], b->evs.ev[i + 1]);
     b->enc_timed = true;

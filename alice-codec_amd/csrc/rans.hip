@@ -361,9 +361,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
 // an exact scalar-lane loop.
 // ----------------------------------------------------------------------------------
 
-constexpr int kDecBlocks = 16;                 // 64-symbol blocks per fast tile
-constexpr int kDecTile = kDecBlocks * 64;      // 1024 symbols
-constexpr int kDecWinBytes = 9 * 64 * 4;        // stream window held in 9 VGPRs (big-endian dwords)
+constexpr int kDecBlocks = 64;                 // 64-symbol blocks per fast tile
+constexpr int kDecTile = kDecBlocks * 64;      // 4096 symbols
+constexpr int kDecWinBytes = 33 * 64 * 4;       // stream window held in 33 VGPRs (big-endian dwords): 2 B/symbol + slack
 constexpr int kDecWinLds = kDecWinBytes;
 
 // The tile body is generated (gen/gen_rans_decode_asm.py -> rans_decode_tile.inc, which documents the
@@ -376,13 +376,13 @@ constexpr int kDecWinLds = kDecWinBytes;
 #include "rans_decode_tile.inc"
 
 // Decodes nblk*64 symbols on the fast path.  tab_addr / win_addr / rec_addr are this lane's LDS byte
-// addresses (base + 4*lane).  pos = byte offset of the next stream byte inside the window.
-__device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, uint32_t tab_addr, uint32_t win_addr,
-                                              uint32_t rec_addr, uint32_t nblk) {
+// addresses (base + 4*lane; the record is 2 bytes per lane).  pos = byte offset of the next stream byte inside the window.
+__device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, uint32_t ftab_addr, uint32_t btab_addr,
+                                              uint32_t win_addr, uint32_t rec_addr, uint32_t nblk) {
     uint32_t xo, po;
     asm volatile(ALICE_DEC_TILE_ASM
                  : [xo] "=&s"(xo), [po] "=&s"(po), [ra] "+v"(rec_addr)
-                 : [xi] "s"(x), [pi] "s"(pos), [nb] "s"(nblk), [ta] "v"(tab_addr), [wa] "v"(win_addr)
+                 : [xi] "s"(x), [pi] "s"(pos), [nb] "s"(nblk), [ta] "v"(ftab_addr), [tb] "v"(btab_addr), [wa] "v"(win_addr)
                  : ALICE_DEC_TILE_CLOBBERS);
     x = xo;
     pos = po;
@@ -390,22 +390,36 @@ __device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, uint32
 
 __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* __restrict__ descs,
                                                          RansResult* __restrict__ results) {
-    __shared__ uint32_t slot_tab[kProbScale];                         // freq | (slot - cum) << 16
+    // x' = freq * (x >> 12) + slot - cum is evaluated as umulhi(F', x) + B' with F' = freq << 20 and
+    // B' = slot - cum - ((freq * slot) >> 12): with x = 4096 h + slot, floor(freq * x / 4096) =
+    // freq * h + floor(freq * slot / 4096), which saves the shift in the chain.  freq = 4096 would overflow
+    // F'; there F' = 2^32 - 1 (umulhi gives x - 1 for x >= 1) and B' carries the + 1.
+    __shared__ uint32_t ftab[kProbScale];
+    __shared__ uint32_t btab[kProbScale];
     __shared__ uint8_t c2s[kProbScale];                               // cum_to_sym
+    __shared__ uint32_t symtab[256];                                  // freq | cum << 16 (exact slow path)
     __shared__ __attribute__((aligned(16))) uint8_t win[kDecWinLds];
-    __shared__ uint32_t rec[kDecTile];                                // pre-update states of a fast tile
+    __shared__ __attribute__((aligned(16))) uint16_t rec[kDecTile];   // low 16 bits of the pre-update states
     __shared__ __attribute__((aligned(16))) uint8_t obuf[kDecTile];
 
     const RansDecodeDesc d = descs[blockIdx.x];
     const int lane = threadIdx.x;
     uint32_t flags = 0u;
 
+    auto entry = [](uint32_t f, uint32_t c, uint32_t s, uint32_t& fo, uint32_t& bo) {
+        if (f >= kProbScale) { fo = 0xFFFFFFFFu; bo = (s - c) - s + 1u; }           // only f == 4096 can own slots
+        else { fo = f << 20; bo = (s - c) - ((f * s) >> kProbBits); }
+    };
     // cum_to_sym is zero-initialised (src/rans.rs:135): default every slot to symbol 0
     {
         const uint32_t f0 = d.table->enc[0].freq, c0 = d.table->enc[0].cum;
         for (int s = lane; s < (int)kProbScale; s += 64) {
             c2s[s] = 0;
-            slot_tab[s] = (f0 & 0xFFFFu) | ((((uint32_t)s - c0) & 0xFFFFu) << 16);
+            entry(f0, c0, (uint32_t)s, ftab[s], btab[s]);
+        }
+        for (int k = 0; k < 4; ++k) {
+            const int sym = lane * 4 + k;
+            symtab[sym] = (d.table->enc[sym].freq & 0xFFFFu) | (d.table->enc[sym].cum << 16);
         }
         __syncthreads();
         // symbols in index order; their slot ranges are disjoint (cum is a running sum), src/rans.rs:136-144
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             if (end > kProbScale) end = kProbScale;
             for (uint32_t s = c; s < end; ++s) {
                 c2s[s] = (uint8_t)sym;
-                slot_tab[s] = f | ((s - c) << 16);
+                entry(f, c, s, ftab[s], btab[s]);
             }
         }
         __syncthreads();
@@ -470,13 +484,13 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             uint32_t prel = (uint32_t)(pos - wbase);
             uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
             prel = (uint32_t)__builtin_amdgcn_readfirstlane((int)prel);
-            dec_tile_fast(xs, prel, (uint32_t)(uintptr_t)slot_tab + 4u * lane, (uint32_t)(uintptr_t)win + 4u * lane,
-                          (uint32_t)(uintptr_t)rec + 4u * lane, (uint32_t)kDecBlocks);
+            dec_tile_fast(xs, prel, (uint32_t)(uintptr_t)ftab + 4u * lane, (uint32_t)(uintptr_t)btab + 4u * lane,
+                          (uint32_t)(uintptr_t)win + 4u * lane, (uint32_t)(uintptr_t)rec + 2u * lane, (uint32_t)kDecBlocks);
             x = xs;
             pos = wbase + prel;
             pending = false;  // the fast path renormalises right after each update
             __syncthreads();
-            for (int i = lane; i < kDecTile; i += 64) obuf[i] = c2s[rec[i] & (kProbScale - 1u)];
+            for (int i = lane; i < kDecTile; i += 64) obuf[i] = c2s[(uint32_t)rec[i] & (kProbScale - 1u)];
             got = (uint32_t)kDecTile;
             ++n_fast;
         } else {
@@ -499,10 +513,11 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
                         }
                         if (starved) break;
                     }
-                    const uint32_t slot = xs & (kProbScale - 1u);
-                    const uint32_t e = slot_tab[slot];
-                    xs = (e & 0xFFFFu) * (xs >> kProbBits) + (e >> 16);
-                    obuf[j] = c2s[slot];
+                    const uint32_t slot = xs & (kProbScale - 1u);                 // src/rans.rs:353
+                    const uint32_t sy = c2s[slot];                                // :356
+                    const uint32_t fc = symtab[sy];
+                    xs = (fc & 0xFFFFu) * (xs >> kProbBits) + slot - (fc >> 16);  // :361-362 (mod 2^32)
+                    obuf[j] = (uint8_t)sy;
                     pend = true;
                     ++j;
                 }

@@ -111,12 +111,14 @@ AliceBatch *alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t f
                                      uint8_t quality, uint8_t wavelet_type);
 void alice_codec_batch_destroy(AliceBatch *batch);
 /* d_rgb: device pointer to n_chunks * width*height*frames*3 bytes.  hip_stream: hipStream_t (NULL = default).
- * Asynchronous; the .alc buffers stay on the device. Returns an ALICE_* code. */
+ * Runs the transforms, waits for them once to size the stream regions from the histograms, then queues the
+ * entropy coding and the .alc assembly asynchronously; the .alc buffers stay on the device.
+ * d_rgb must stay valid until alice_codec_batch_encode_finish. Returns an ALICE_* code. */
 int alice_codec_batch_encode(AliceBatch *batch, const void *d_rgb, void *hip_stream);
 /* waits for the encode, checks per-chain flags, writes the .alc size of each chunk */
 int alice_codec_batch_encode_finish(AliceBatch *batch, uint64_t *sizes /* n_chunks */);
 const void *alice_codec_batch_alc_ptr(const AliceBatch *batch, uint32_t chunk); /* device pointer */
-uint64_t alice_codec_batch_alc_stride(const AliceBatch *batch);
+uint64_t alice_codec_batch_alc_stride(const AliceBatch *batch); /* valid after alice_codec_batch_encode */
 /* copies the n_chunks finished .alc buffers back to back into d_dst (device), in chunk order:
  * the contiguous byte blob a rank contributes to the multi-GPU gather. Asynchronous. */
 int alice_codec_batch_pack_alc(AliceBatch *batch, const uint64_t *sizes, void *d_dst, uint64_t dst_capacity,

@@ -63,6 +63,8 @@ PROBE_KERNEL(k_flbit_m0_movrels, "s_flbit_i32_b32 m0, s44\n\t s_nop 0\n\t s_movr
 PROBE_KERNEL(k_m0_write, "s_mov_b32 m0, s43\n\t")
 PROBE_KERNEL(k_dec2_core, "s_bfe_u32 s45, s40, 0x60006\n\t s_set_gpr_idx_on s43, 0x1\n\t v_readlane_b32 s47, v40, s40\n\t v_readlane_b32 s46, v41, s40\n\t s_lshr_b32 s45, s41, 9\n\t s_lshr_b32 s45, s41, 3\n\t s_set_gpr_idx_on s43, 0x1\n\t v_readlane_b32 s45, v42, s41\n\t s_lshr_b32 s45, s40, 12\n\t v_writelane_b32 v44, s40, 3\n\t s_mul_i32 s47, s47, s45\n\t s_add_u32 s40, s47, s46\n\t s_flbit_i32_b32 m0, s44\n\t s_nop 0\n\t s_movrels_b32 s45, s42\n\t s_lshl_b64 s[40:41], s[40:41], s43\n\t s_add_u32 s41, s41, s43\n\t")
 PROBE_KERNEL(k_dec2_core_idx, "s_bfe_u32 s45, s40, 0x60006\n\t s_set_gpr_idx_idx s43\n\t v_readlane_b32 s47, v40, s40\n\t v_readlane_b32 s46, v41, s40\n\t s_lshr_b32 s45, s41, 9\n\t s_lshr_b32 s45, s41, 3\n\t s_set_gpr_idx_idx s43\n\t v_readlane_b32 s45, v42, s41\n\t s_lshr_b32 s45, s40, 12\n\t v_writelane_b32 v44, s40, 3\n\t s_mul_i32 s47, s47, s45\n\t s_add_u32 s40, s47, s46\n\t s_cmp_lt_u32 s40, s44\n\t s_cselect_b32 s45, 8, 0\n\t s_cmp_lt_u32 s40, s42\n\t s_cselect_b32 s45, 16, s45\n\t s_lshl_b64 s[40:41], s[40:41], s43\n\t s_add_u32 s41, s41, s43\n\t")
+PROBE_KERNEL(k_dec4_core, "s_lshr_b32 s45, s40, 12\n\t s_bfe_u32 s46, s40, 0x60006\n\t s_set_gpr_idx_on s43, 0x1\n\t v_writelane_b32 v44, s40, 3\n\t v_readlane_b32 s47, v40, s40\n\t v_readlane_b32 s46, v41, s40\n\t s_mul_i32 s47, s47, s45\n\t s_add_u32 s40, s47, s46\n\t s_flbit_i32_b32 m0, s44\n\t s_mov_b32 s46, s41\n\t s_movrels_b32 s45, s42\n\t s_lshl_b64 s[40:41], s[40:41], s43\n\t s_lshl_b64 s[46:47], s[46:47], s43\n\t s_sub_u32 s45, s45, s43\n\t")
+PROBE_KERNEL(k_dec4_pair, "s_lshr_b32 s45, s40, 12\n\t s_bfe_u32 s46, s40, 0x60006\n\t s_set_gpr_idx_on s43, 0x1\n\t v_writelane_b32 v44, s40, 3\n\t v_readlane_b32 s47, v40, s40\n\t v_readlane_b32 s46, v41, s40\n\t s_mul_i32 s47, s47, s45\n\t s_add_u32 s40, s47, s46\n\t s_flbit_i32_b32 m0, s44\n\t s_mov_b32 s46, s41\n\t s_movrels_b32 s45, s42\n\t s_lshl_b64 s[40:41], s[40:41], s43\n\t s_lshl_b64 s[46:47], s[46:47], s43\n\t s_sub_u32 s45, s45, s43\n\ts_lshr_b32 s45, s40, 12\n\t s_bfe_u32 s46, s40, 0x60006\n\t s_set_gpr_idx_on s43, 0x1\n\t v_writelane_b32 v44, s40, 3\n\t v_readlane_b32 s47, v40, s40\n\t v_readlane_b32 s46, v41, s40\n\t s_mul_i32 s47, s47, s45\n\t s_add_u32 s40, s47, s46\n\t s_flbit_i32_b32 m0, s44\n\t s_mov_b32 s46, s41\n\t s_movrels_b32 s45, s42\n\t s_lshl_b64 s[40:41], s[40:41], s43\n\t s_lshl_b64 s[46:47], s[46:47], s43\n\t s_sub_u32 s45, s45, s43\n\ts_cmp_lt_u32 s42, s43\n\t s_cbranch_scc1 9f\n\t 9:\n\t")
 PROBE_KERNEL(k_enc_core, "v_add_u32_dpp v40, v44, v41 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t v_cmp_ge_u32_e64 s[46:47], v40, v41\n\t v_cmp_ge_u32_e32 vcc, v40, v42\n\t s_nop 0\n\t v_cndmask_b32_e64 v45, 0, 8, s[46:47]\n\t v_cndmask_b32_e64 v45, v45, 16, vcc\n\t v_lshrrev_b32_e32 v45, v45, v40\n\t v_mul_hi_u32 v43, v45, v41\n\t v_lshrrev_b32_e32 v43, v42, v43\n\t v_mad_i32_i24 v44, v43, v42, v45\n\t s_nop 1\n\t")
 
 struct T { const char* name; void (*fn)(unsigned long long*, uint32_t); };
@@ -77,7 +79,7 @@ int main() {
     {"set_idx;v_readlane;s_and chain", k_setidx_readlane}, {"v_writelane", k_writelane},
     {"cmp+branch not taken", k_branch_nt}, {"cmp+branch taken (skip 1)", k_branch_t}, {"cmp+branch taken (skip 16)", k_branch_t_far},
     {"s_nop 0", k_snop0}, {"s_nop 1", k_snop1}, {"s_cmp+s_cselect dep", k_cselect},
-    {"s_set_gpr_idx_on", k_setidx_on}, {"s_set_gpr_idx_idx", k_setidx_idx}, {"s_flbit", k_flbit}, {"s_flbit m0;nop;s_movrels", k_flbit_m0_movrels}, {"s_mov m0", k_m0_write}, {"decode v3 core (17 instr, idx_on+flbit)", k_dec2_core}, {"decode v3 core (18 instr, idx_idx+cmp/csel)", k_dec2_core_idx}, {"decode core (9 instr)", k_dec_core}, {"encode ripple step (11 instr)", k_enc_core}};
+    {"s_set_gpr_idx_on", k_setidx_on}, {"s_set_gpr_idx_idx", k_setidx_idx}, {"s_flbit", k_flbit}, {"s_flbit m0;nop;s_movrels", k_flbit_m0_movrels}, {"s_mov m0", k_m0_write}, {"decode v3 core (17 instr, idx_on+flbit)", k_dec2_core}, {"decode v3 core (18 instr, idx_idx+cmp/csel)", k_dec2_core_idx}, {"decode v4 symbol (14 instr)", k_dec4_core}, {"decode v4 pair (28 instr + cmp + untaken branch)", k_dec4_pair}, {"decode core (9 instr)", k_dec_core}, {"encode ripple step (11 instr)", k_enc_core}};
   double base = 0;
   for (auto& t : tests) {
     unsigned long long best = ~0ull;
