@@ -418,6 +418,8 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
         HIP_TRY(hipStreamSynchronize(st));
         for (int c = 0; c < 3 * B; ++c) cap = std::max(cap, estimate_stream_cap(&hist[(size_t)c * 256], d.padded));
         cap = std::min(round_up(cap, 256), worst_cap(d));
+        // test hook: pretend the estimate was far too small, to exercise the overflow-and-retry path
+        if (getenv("ALICE_CODEC_TEST_TINY_CAP")) cap = 4352;
     }
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);

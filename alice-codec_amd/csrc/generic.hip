@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict_
         unsigned long long total = kAlcHeaderBytes;
         for (int c = 0; c < 3; ++c) {
             uint8_t* h = p + kFixedHeaderBytes + c * kChannelHeaderBytes;
-            const unsigned long long len = res[chunk * 3 + c].len;
+            // a chain that overflowed its region produced no stream: the host sees the flag and encodes again
+            const unsigned long long len = (res[chunk * 3 + c].flags & kRansOverflow) ? 0ull : res[chunk * 3 + c].len;
             put_u32le(h, (uint32_t)len);            // compressed_len as u32 (src/pipeline.rs:489)
             put_u32le(h + 4, (uint32_t)step);
             put_u32le(h + 8, (uint32_t)step);       // dead_zone = step (Quantizer::new)
@@ -361,7 +362,9 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(uint8_t* __restric
     uint8_t* dst = alc + (size_t)chunk * alc_stride + kAlcHeaderBytes;
     const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, nthreads = (unsigned long long)gridDim.x * 256;
     for (int c = 0; c < 3; ++c) {
-        const unsigned long long len = res[chunk * 3 + c].len;
+        // never touch memory for a chain that overflowed its region (its length exceeds the capacity)
+        const RansResult rr = res[chunk * 3 + c];
+        const unsigned long long len = ((rr.flags & kRansOverflow) || rr.len > cap) ? 0ull : rr.len;
         const uint8_t* src = streams + ((size_t)chunk * 3 + c) * cap + (cap - len);
         // bytes up to the first 16-byte boundary of dst, then 16 B stores fed by (possibly unaligned) 4 B loads
         unsigned long long head = (16u - (unsigned)((uintptr_t)dst & 15u)) & 15u;

@@ -244,27 +244,29 @@ __device__ __forceinline__ I4 lift4(const I4& base, const I4& a, const I4& b, in
 constexpr int kHistReplicas = 8;
 constexpr int kHistWords = kHistReplicas * 256 + 256;
 
-__device__ __forceinline__ uint32_t quant_sym4(const I4& x, int step, uint32_t magic, uint32_t* lh, int rep_base, int dummy) {
+// Quantizer::quantize (src/quant.rs:89-97, dead zone = step) followed by to_symbols (:555-560), branch-free:
+//   q = (|v| - step/2) / step for |v| >= step, else 0.  For |v| < step the quotient of the saturating
+//   difference is already 0, so the dead-zone test disappears; symbol = 2q - (v > 0), and the one case that
+//   would go negative (q = 0, v > 0) is exactly the case to_symbols maps to 0.
+template <bool STEP1>
+__device__ __forceinline__ uint32_t quant_sym4(const I4& x, int hdz, uint32_t magic, uint32_t* lh, int rep_base, int dummy) {
     uint32_t packed = 0u;
-    const int hdz = step / 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int val = x.v[i];
-        const int mag = val < 0 ? -val : val;
-        uint32_t s = 0u;
-        if (mag >= step) {  // dead zone = step (Quantizer::new, src/quant.rs:70-75)
-            const uint32_t adj = (uint32_t)(mag - hdz);
-            const uint32_t q = (step == 1) ? adj : __umulhi(adj, magic);
-            // q can be 0 just above the dead zone; to_symbols maps 0 -> 0 (src/quant.rs:557)
-            s = (q == 0u) ? 0u : (((val > 0) ? (2u * q - 1u) : (2u * q)) & 0xFFu);  // `as u8`
-        }
+        const int neg = -val;
+        const uint32_t mag = (uint32_t)max(val, neg);
+        const uint32_t adj = mag > (uint32_t)hdz ? mag - (uint32_t)hdz : 0u;      // saturating
+        const uint32_t q = STEP1 ? adj : __umulhi(adj, magic);                     // exact: adj * step < 2^32
+        const int t = (int)(q << 1) + (neg >> 31);                                 // 2q - (v > 0)
+        const uint32_t s = (uint32_t)max(t, 0) & 0xFFu;                            // `as u8`
         atomicAdd(&lh[s ? (rep_base + (int)s) : dummy], 1u);
         packed |= s << (8 * i);
     }
     return packed;
 }
 
-template <int NS>
+template <int NS, bool STEP1>
 __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ mid, uint8_t* __restrict__ sym,
                                                     uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf, int step,
                                                     uint32_t magic) {
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
     const int ch = blockIdx.y;
     const int pf = d.pf, half = pf / 2;
     const int rep_base = (tid & (kHistReplicas - 1)) * 256, dummy = kHistReplicas * 256 + tid;
+    const int hdz = step / 2;
     uint32_t emitted = 0u;
     if (idx < plane) {
         emitted = 4u * (uint32_t)pf;
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
                     e1p = lift4<false>(e0p, (j >= 2) ? o1pp : o1p, o1p, cf.c[1]);
                 }
                 if (NS == 2) {
-                    const uint32_t lo = quant_sym4(e1p, step, magic, lh, rep_base, dummy);
-                    const uint32_t hi = quant_sym4(o1p, step, magic, lh, rep_base, dummy);
+                    const uint32_t lo = quant_sym4<STEP1>(e1p, hdz, magic, lh, rep_base, dummy);
+                    const uint32_t hi = quant_sym4<STEP1>(o1p, hdz, magic, lh, rep_base, dummy);
                     dst[(size_t)(j - 1) * plane4] = lo;
                     dst[(size_t)(half + j - 1) * plane4] = hi;
                 } else {
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
                         const I4 o2pp = lift4<false>(o1pp, e1pp, have1 ? e1p : e1pp, cf.c[2]);
                         // U2 for pair j-2: left neighbour O2[j-3] or mirror O2[0]
                         const I4 e2pp = lift4<false>(e1pp, (j >= 3) ? o2ppp : o2pp, o2pp, cf.c[3]);
-                        const uint32_t lo = quant_sym4(e2pp, step, magic, lh, rep_base, dummy);
-                        const uint32_t hi = quant_sym4(o2pp, step, magic, lh, rep_base, dummy);
+                        const uint32_t lo = quant_sym4<STEP1>(e2pp, hdz, magic, lh, rep_base, dummy);
+                        const uint32_t hi = quant_sym4<STEP1>(o2pp, hdz, magic, lh, rep_base, dummy);
                         dst[(size_t)(j - 2) * plane4] = lo;
                         dst[(size_t)(half + j - 2) * plane4] = hi;
                         o2ppp = o2pp;
@@ -585,8 +588,13 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
     const size_t plane = (size_t)d.pw * d.ph;
     const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
     dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
-    if (ls.n == 4) hipLaunchKernelGGL((fwd_t_kernel<4>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
-    else hipLaunchKernelGGL((fwd_t_kernel<2>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+    if (ls.n == 4) {
+        if (step == 1) hipLaunchKernelGGL((fwd_t_kernel<4, true>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+        else hipLaunchKernelGGL((fwd_t_kernel<4, false>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+    } else {
+        if (step == 1) hipLaunchKernelGGL((fwd_t_kernel<2, true>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+        else hipLaunchKernelGGL((fwd_t_kernel<2, false>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+    }
     return true;
 }
 

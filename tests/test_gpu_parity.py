@@ -128,6 +128,20 @@ def test_decoder_follows_desynchronised_streams(gpu_codec, oracle_mod):
         assert np.array_equal(got, ref), trial
 
 
+def test_stream_capacity_overflow_is_retried(gpu_codec, oracle_mod, monkeypatch):
+    """Stream regions are sized from the histograms; if a chain ever outgrew its region the kernels must not
+    touch memory outside it and the host must encode again with the worst-case capacity.  The test hook shrinks
+    the first capacity to 4352 bytes so that path runs."""
+    w, h, f = 96, 64, 16
+    rgb = np.random.default_rng(21).integers(0, 256, w * h * f * 3, dtype=np.uint8)
+    ref = oracle_mod.encode(rgb, w, h, f, 90, 1)
+    assert len(ref) > 3138 + 3 * 4352
+    monkeypatch.setenv("ALICE_CODEC_TEST_TINY_CAP", "1")
+    got = gpu_codec.FrameEncoder.with_wavelet(90, gpu_codec.WaveletType.Cdf97).encode(rgb, w, h, f).to_bytes()
+    monkeypatch.delenv("ALICE_CODEC_TEST_TINY_CAP")
+    assert got == ref
+
+
 def test_decode_validation_errors(gpu_codec, oracle_mod):  # src/pipeline.rs:566-576
     alc = bytearray(oracle_mod.encode(oracle_mod.make_gradient(4, 4, 2), 4, 4, 2, 80))
     bad = bytearray(alc); bad[18 + 12: 18 + 16] = (31).to_bytes(4, "little")  # num_symbols != padded
