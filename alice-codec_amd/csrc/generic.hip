@@ -256,16 +256,39 @@ __global__ __launch_bounds__(256) void from_symbols_kernel(const uint8_t* __rest
     }
 }
 
+// build_histogram (src/quant.rs:594-600).  16 symbols per thread per step; the dominant zero symbol is
+// counted in a register (byte-wise zero test), the others go to 8 LDS replicas of the bins.
 __global__ __launch_bounds__(256) void histogram_kernel(const uint8_t* __restrict__ sym, unsigned long long n,
                                                         uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lh[256];
-    lh[threadIdx.x] = 0u;
+    __shared__ uint32_t lh[8 * 256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8 * 256; i += 256) lh[i] = 0u;
     __syncthreads();
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * 256)
-        atomicAdd(&lh[sym[i]], 1u);
+    uint32_t* my = lh + (tid & 7) * 256;
+    unsigned long long zeros = 0ull;
+    const unsigned long long nvec = (((uintptr_t)sym & 15u) == 0u) ? n / 16 : 0ull;
+    for (unsigned long long v = (unsigned long long)blockIdx.x * 256 + tid; v < nvec; v += (unsigned long long)gridDim.x * 256) {
+        const uint4 q = ((const uint4*)sym)[v];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t s = (w[k] >> (8 * b)) & 0xFFu;
+                if (s) atomicAdd(&my[s], 1u); else ++zeros;
+            }
+        }
+    }
+    for (unsigned long long i = nvec * 16 + (unsigned long long)blockIdx.x * 256 + tid; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const uint32_t s = sym[i];
+        if (s) atomicAdd(&my[s], 1u); else ++zeros;
+    }
+    if (zeros) atomicAdd(&lh[0], (uint32_t)zeros);
     __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    uint32_t cnt = 0u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cnt += lh[r * 256 + tid];
+    if (cnt) atomicAdd(&hist[tid], cnt);
 }
 
 __global__ __launch_bounds__(256) void sq_diff_sum_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,

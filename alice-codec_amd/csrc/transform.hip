@@ -25,6 +25,8 @@
 // Intermediates: the forward path stores i16 (from u8 input every value in the transform stays
 // below 2^13 in magnitude, SURVEY.md section 7 hard part 5); the inverse path stores i32 because a
 // desynchronised decoder feeds it arbitrary symbols (i16 when the host proves the bound).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -248,7 +250,7 @@ constexpr int kHistWords = kHistReplicas * 256 + 256;
 //   q = (|v| - step/2) / step for |v| >= step, else 0.  For |v| < step the quotient of the saturating
 //   difference is already 0, so the dead-zone test disappears; symbol = 2q - (v > 0), and the one case that
 //   would go negative (q = 0, v > 0) is exactly the case to_symbols maps to 0.
-template <bool STEP1>
+template <bool STEP1, bool HIST>
 __device__ __forceinline__ uint32_t quant_sym4(const I4& x, int hdz, uint32_t magic, uint32_t* lh, int rep_base, int dummy) {
     uint32_t packed = 0u;
 #pragma unroll
@@ -260,13 +262,13 @@ __device__ __forceinline__ uint32_t quant_sym4(const I4& x, int hdz, uint32_t ma
         const uint32_t q = STEP1 ? adj : __umulhi(adj, magic);                     // exact: adj * step < 2^32
         const int t = (int)(q << 1) + (neg >> 31);                                 // 2q - (v > 0)
         const uint32_t s = (uint32_t)max(t, 0) & 0xFFu;                            // `as u8`
-        atomicAdd(&lh[s ? (rep_base + (int)s) : dummy], 1u);
+        if (HIST) atomicAdd(&lh[s ? (rep_base + (int)s) : dummy], 1u);
         packed |= s << (8 * i);
     }
     return packed;
 }
 
-template <int NS, bool STEP1>
+template <int NS, bool STEP1, bool HIST>
 __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ mid, uint8_t* __restrict__ sym,
                                                     uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf, int step,
                                                     uint32_t magic) {
@@ -309,8 +311,8 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
                     e1p = lift4<false>(e0p, (j >= 2) ? o1pp : o1p, o1p, cf.c[1]);
                 }
                 if (NS == 2) {
-                    const uint32_t lo = quant_sym4<STEP1>(e1p, hdz, magic, lh, rep_base, dummy);
-                    const uint32_t hi = quant_sym4<STEP1>(o1p, hdz, magic, lh, rep_base, dummy);
+                    const uint32_t lo = quant_sym4<STEP1, HIST>(e1p, hdz, magic, lh, rep_base, dummy);
+                    const uint32_t hi = quant_sym4<STEP1, HIST>(o1p, hdz, magic, lh, rep_base, dummy);
                     dst[(size_t)(j - 1) * plane4] = lo;
                     dst[(size_t)(half + j - 1) * plane4] = hi;
                 } else {
@@ -319,8 +321,8 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
                         const I4 o2pp = lift4<false>(o1pp, e1pp, have1 ? e1p : e1pp, cf.c[2]);
                         // U2 for pair j-2: left neighbour O2[j-3] or mirror O2[0]
                         const I4 e2pp = lift4<false>(e1pp, (j >= 3) ? o2ppp : o2pp, o2pp, cf.c[3]);
-                        const uint32_t lo = quant_sym4<STEP1>(e2pp, hdz, magic, lh, rep_base, dummy);
-                        const uint32_t hi = quant_sym4<STEP1>(o2pp, hdz, magic, lh, rep_base, dummy);
+                        const uint32_t lo = quant_sym4<STEP1, HIST>(e2pp, hdz, magic, lh, rep_base, dummy);
+                        const uint32_t hi = quant_sym4<STEP1, HIST>(o2pp, hdz, magic, lh, rep_base, dummy);
                         dst[(size_t)(j - 2) * plane4] = lo;
                         dst[(size_t)(half + j - 2) * plane4] = hi;
                         o2ppp = o2pp;
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
             e0n = e0nn; o0n = o0nn;
         }
     }
+    if (!HIST) return;
     __syncthreads();
     // fold the replicas; bin 0 = symbols emitted by this block - nonzero symbols
     __shared__ uint32_t tot_sh, nz_sh;
@@ -588,13 +591,19 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
     const size_t plane = (size_t)d.pw * d.ph;
     const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
     dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
+    // ALICE_CODEC_SPLIT_HIST=1: histogram in a separate pass over the symbols instead of fused LDS atomics (A/B switch)
+    static const bool split_hist = getenv("ALICE_CODEC_SPLIT_HIST") != nullptr;
+#define ALICE_FWD_T(NS_, S1_, H_) hipLaunchKernelGGL((fwd_t_kernel<NS_, S1_, H_>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic)
     if (ls.n == 4) {
-        if (step == 1) hipLaunchKernelGGL((fwd_t_kernel<4, true>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
-        else hipLaunchKernelGGL((fwd_t_kernel<4, false>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+        if (split_hist) { if (step == 1) ALICE_FWD_T(4, true, false); else ALICE_FWD_T(4, false, false); }
+        else { if (step == 1) ALICE_FWD_T(4, true, true); else ALICE_FWD_T(4, false, true); }
     } else {
-        if (step == 1) hipLaunchKernelGGL((fwd_t_kernel<2, true>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
-        else hipLaunchKernelGGL((fwd_t_kernel<2, false>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic);
+        if (split_hist) { if (step == 1) ALICE_FWD_T(2, true, false); else ALICE_FWD_T(2, false, false); }
+        else { if (step == 1) ALICE_FWD_T(2, true, true); else ALICE_FWD_T(2, false, true); }
     }
+#undef ALICE_FWD_T
+    if (split_hist)
+        for (int c = 0; c < 3; ++c) launch_histogram(d_sym + (size_t)c * d.padded, d.padded, d_hist + c * 256, st);
     return true;
 }
 

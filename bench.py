@@ -98,7 +98,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "16")),
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "96")),
                     help="1080p x 64 chunks in flight per GPU (3 rANS chains each)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of chunk 0 in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
