@@ -415,3 +415,25 @@ def test_full_size_1080p64_cdf97_q80(gpu_codec, oracle_mod):   # BASELINE.json c
 
 def test_full_size_1080p64_cdf53_q80(gpu_codec, oracle_mod):   # BASELINE.json configs[1]
     _full_size(gpu_codec, oracle_mod, 0, 80, False)
+
+
+def test_4k_frames_cdf97_q90(gpu_codec, oracle_mod):
+    """The spatial size and quality of BASELINE.json configs[3] (3840x2160, q=90) on 6 frames: large tile grids,
+    more than 65535 tiles per launch dimension product, a frame count that is not a multiple of 4."""
+    w, h, f = 3840, 2160, 6
+    rgb = smooth_rgb(w, h, f, seed=77)
+    ref = oracle_mod.encode(rgb, w, h, f, 90, 1)
+    chunk = gpu_codec.FrameEncoder.with_wavelet(90, gpu_codec.WaveletType.Cdf97).encode(rgb, w, h, f)
+    got = chunk.to_bytes()
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(ref).hexdigest(), first_diff(got, ref)
+    assert np.array_equal(gpu_codec.FrameDecoder().decode(chunk), oracle_mod.decode(ref))
+
+
+def test_unaligned_widths_and_heights(gpu_codec, oracle_mod):
+    """Widths that are not multiples of 4 (byte-wise RGB loads/stores), tiles that straddle every border case."""
+    for w, h, f, k in ((130, 41, 4, 1), (257, 83, 3, 0), (127, 40, 2, 2), (129, 121, 5, 1), (514, 90, 2, 1)):
+        rgb = np.random.default_rng(w + h).integers(0, 256, w * h * f * 3, dtype=np.uint8)
+        ref = oracle_mod.encode(rgb, w, h, f, 85, k)
+        chunk = gpu_codec.FrameEncoder.with_wavelet(85, gpu_codec.WaveletType(k)).encode(rgb, w, h, f)
+        assert chunk.to_bytes() == ref, (w, h, f, k)
+        assert np.array_equal(gpu_codec.FrameDecoder().decode(chunk), oracle_mod.decode(ref)), (w, h, f, k)
