@@ -451,26 +451,38 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
     while (done < d.n) {
         const unsigned long long remain = d.n - done;
         const uint32_t want = remain < (unsigned long long)kDecTile ? (uint32_t)remain : (uint32_t)kDecTile;
-        // stage the stream window [wbase, wbase + 2304) (zero beyond len)
-        const unsigned long long wbase = pos & ~3ull;
+        // Stage the stream window [wbase, wbase + kDecWinLds) into LDS (zero beyond len).  The base is chosen so
+        // that its global address is dword aligned; when the whole window lies inside the stream all 33 dword
+        // loads of a lane are issued back to back (one memory latency per tile instead of 33).
+        unsigned long long wbase = pos & ~3ull;
+        {
+            const unsigned long long mis = (unsigned long long)((uintptr_t)(d.in + pos) & 3u);
+            if (pos >= mis) wbase = pos - mis;
+        }
+        const bool whole = (len - wbase >= (unsigned long long)kDecWinLds) && ((((uintptr_t)(d.in + wbase)) & 3u) == 0u);
         __syncthreads();
-        for (int i = lane * 4; i < kDecWinLds; i += 64 * 4) {
-            const unsigned long long o = wbase + (unsigned long long)i;
-            uint32_t w = 0u;
-            if (o + 4ull <= len && ((((uintptr_t)(d.in + o)) & 3u) == 0u)) {
-                w = *(const uint32_t*)(d.in + o);
-            } else {
+        if (whole) {
+            const uint32_t* g = (const uint32_t*)(d.in + wbase) + lane;
+            uint32_t wv[kDecWinLds / 256];
+#pragma unroll
+            for (int k = 0; k < kDecWinLds / 256; ++k) wv[k] = g[k * 64];
+#pragma unroll
+            for (int k = 0; k < kDecWinLds / 256; ++k) ((uint32_t*)win)[k * 64 + lane] = wv[k];
+        } else {
+            for (int i = lane * 4; i < kDecWinLds; i += 64 * 4) {
+                const unsigned long long o = wbase + (unsigned long long)i;
+                uint32_t w = 0u;
                 for (int b = 0; b < 4; ++b)
                     if (o + (unsigned long long)b < len) w |= (uint32_t)d.in[o + b] << (8 * b);
+                *(uint32_t*)(win + i) = w;
             }
-            *(uint32_t*)(win + i) = w;
         }
         __syncthreads();
 
         // the owed renormalisation first (src/rans.rs:365-368); it needs at most a few window bytes
         // unless the state is 0, which the exact loop below handles byte by byte
         uint32_t got = 0u;
-        bool fast = (want == (uint32_t)kDecTile) && (len - wbase >= (unsigned long long)kDecWinLds);
+        bool fast = (want == (uint32_t)kDecTile) && whole;
         if (fast && pending) {
             uint32_t xs = x;
             unsigned long long ps = pos;
@@ -490,8 +502,17 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             pos = wbase + prel;
             pending = false;  // the fast path renormalises right after each update
             __syncthreads();
-            for (int i = lane; i < kDecTile; i += 64) obuf[i] = c2s[(uint32_t)rec[i] & (kProbScale - 1u)];
-            got = (uint32_t)kDecTile;
+            // symbols from the recorded states, 4 per lane; straight to global memory when the output is aligned
+            const bool out_aligned = (((uintptr_t)(d.out + done)) & 3u) == 0u;
+            for (int i = lane * 4; i < kDecTile; i += 256) {
+                const uint2 r4 = *(const uint2*)&rec[i];
+                const uint32_t packed = (uint32_t)c2s[r4.x & (kProbScale - 1u)] | ((uint32_t)c2s[(r4.x >> 16) & (kProbScale - 1u)] << 8) |
+                                        ((uint32_t)c2s[r4.y & (kProbScale - 1u)] << 16) | ((uint32_t)c2s[(r4.y >> 16) & (kProbScale - 1u)] << 24);
+                if (out_aligned) *(uint32_t*)(d.out + done + i) = packed;
+                else *(uint32_t*)(obuf + i) = packed;
+            }
+            got = out_aligned ? 0u : (uint32_t)kDecTile;   // 0: nothing left in obuf to flush
+            done += out_aligned ? (unsigned long long)kDecTile : 0ull;
             ++n_fast;
         } else {
             ++n_slow;
