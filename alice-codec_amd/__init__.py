@@ -163,6 +163,12 @@ def load_library() -> C.CDLL:
         "alice_codec_rans_decode": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
         "alice_codec_rgb_to_ycocg_r": (C.c_int, [_u8p, C.c_uint64, _i16p, _i16p, _i16p, C.c_uint64]),
         "alice_codec_ycocg_r_to_rgb": (C.c_int, [_i16p, _i16p, _i16p, C.c_uint64, _u8p, C.c_uint64]),
+        "alice_codec_dev_forward_symbols": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, vp, vp, vp]),
+        "alice_codec_dev_inverse_symbols": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, _i32p, vp, vp]),
+        "alice_codec_dev_histogram": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "alice_codec_rans_stream_bound": (C.c_uint64, [_u32p, C.c_uint64]),
+        "alice_codec_dev_rans_encode": (C.c_int, [vp, C.c_uint64, _u32p, vp, C.c_uint64, _u64p, _u64p, vp]),
+        "alice_codec_dev_rans_decode": (C.c_int, [vp, C.c_uint64, _u32p, vp, C.c_uint64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
@@ -192,6 +198,15 @@ def _raise_last(default_code: int = 10):
 def _check(rc: int):
     if rc != 0:
         _raise_last(rc)
+
+
+def _copy_out(ptr, n: int) -> np.ndarray:
+    """Copies n bytes at a C pointer into a fresh array.  (ctypes.string_at takes its size as a C int on this
+    Python, which silently truncates buffers of 2 GiB and more.)"""
+    if n == 0:
+        return np.zeros(0, np.uint8)
+    addr = C.cast(ptr, C.c_void_p).value
+    return np.frombuffer((C.c_uint8 * n).from_address(addr), dtype=np.uint8).copy()
 
 
 def _as_u8(a) -> np.ndarray:
@@ -264,7 +279,7 @@ class EncodedChunk:
         if not p:
             _raise_last()
         try:
-            return C.string_at(p, n.value)
+            return _copy_out(p, n.value).tobytes()
         finally:
             lib.alice_codec_data_free64(p, n.value)
 
@@ -321,7 +336,7 @@ class FrameDecoder:
         if not p:
             _raise_last()
         try:
-            return np.frombuffer(C.string_at(p, n.value), dtype=np.uint8).copy()
+            return _copy_out(p, n.value)
         finally:
             lib.alice_codec_data_free64(p, n.value)
 
@@ -582,7 +597,7 @@ class RansEncoder:
         if not p:
             _raise_last()
         try:
-            return C.string_at(p, n.value)
+            return _copy_out(p, n.value).tobytes()
         finally:
             lib.alice_codec_data_free64(p, n.value)
 

@@ -1167,4 +1167,121 @@ int alice_codec_ycocg_r_to_rgb(const int16_t* y, const int16_t* co, const int16_
     return kOk;
 }
 
+// ---- PART 3: device-resident stage calls (building blocks of the row-slab sharded path) ----
+// Every pointer named d_* is a device pointer; launches go on `hip_stream` and the call returns after the
+// stream has drained (the rANS calls need their result on the host anyway).
+
+int alice_codec_dev_forward_symbols(const void* d_rgb, uint32_t width, uint32_t height, uint32_t frames, uint8_t wavelet_type,
+                                    uint8_t quality, void* d_symbols, void* d_hist, void* hip_stream) {
+    clear_error();
+    if (!d_rgb || !d_symbols) return fail(kNullArgument, "null argument");
+    if (wavelet_type > 2) return fail(kInvalidBitstream, "unknown wavelet type");
+    uint64_t n_pixels = 0;
+    TRY(checked_pixel_count(width, height, frames, &n_pixels));
+    if (n_pixels == 0) return fail(kInvalidDimensions, "invalid dimensions");
+    const ChunkDims d = make_dims(width, height, frames);
+    if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count exceeds u32");
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    EncodeWork w;
+    w.d = d; w.n_chunks = 1;
+    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
+    TRY(w.hist.alloc(3 * 256 * sizeof(uint32_t)));
+    uint32_t* hist = d_hist ? (uint32_t*)d_hist : w.hist.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(hist, 0, 3 * 256 * sizeof(uint32_t), st));
+    const int32_t step = quality_to_step(quality);
+    if (!launch_forward_transform((const uint8_t*)d_rgb, d, wavelet_type, step, w.mid.as<int32_t>(), (uint8_t*)d_symbols, hist, st))
+        TRY(forward_generic((const uint8_t*)d_rgb, d, wavelet_type, step, w, (uint8_t*)d_symbols, hist, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+int alice_codec_dev_inverse_symbols(const void* d_symbols, uint32_t width, uint32_t height, uint32_t frames, uint8_t wavelet_type,
+                                    const int32_t step[3], void* d_rgb, void* hip_stream) {
+    clear_error();
+    if (!d_rgb || !d_symbols || !step) return fail(kNullArgument, "null argument");
+    if (wavelet_type > 2) return fail(kInvalidBitstream, "unknown wavelet type");
+    uint64_t n_pixels = 0;
+    TRY(checked_pixel_count(width, height, frames, &n_pixels));
+    if (n_pixels == 0) return fail(kInvalidDimensions, "invalid dimensions");
+    const ChunkDims d = make_dims(width, height, frames);
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    DecodeWork w;
+    w.d = d; w.n_chunks = 1;
+    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
+    w.mid_ptr = w.mid.as<int32_t>();
+    const InverseBounds ib = inverse_bounds(wavelet_type, step);
+    if (!launch_inverse_transform((const uint8_t*)d_symbols, d, wavelet_type, step, !ib.fast, ib.fast && ib.mid16, w.mid_ptr, (uint8_t*)d_rgb, st))
+        TRY(inverse_generic((const uint8_t*)d_symbols, d, wavelet_type, step, w, (uint8_t*)d_rgb, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+int alice_codec_dev_histogram(const void* d_symbols, uint64_t n, void* d_hist, void* hip_stream) {
+    clear_error();
+    if (!d_hist || (!d_symbols && n)) return fail(kNullArgument, "null argument");
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), st));
+    if (n) launch_histogram((const uint8_t*)d_symbols, n, (uint32_t*)d_hist, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
+uint64_t alice_codec_rans_stream_bound(const uint32_t hist[256], uint64_t n) {
+    if (!hist) return round_up(2 * n + 4 + 64 + 64, 256);
+    const uint64_t worst = round_up(2 * n + 4 + 64 + 64, 256);
+    const uint64_t est = round_up(estimate_stream_cap(hist, n) + 64, 256);
+    return est < worst ? est : worst;
+}
+
+int alice_codec_dev_rans_encode(const void* d_symbols, uint64_t n, const uint32_t hist[256], void* d_out, uint64_t cap,
+                                uint64_t* out_offset, uint64_t* out_len, void* hip_stream) {
+    clear_error();
+    if ((!d_symbols && n) || !hist || !d_out || !out_offset || !out_len) return fail(kNullArgument, "null argument");
+    if (cap < 4 + 64 + 64) return fail(kInvalidBufferSize, "stream region too small");
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    DevBuf dh, dt, dres;
+    TRY(dh.alloc(256 * 4)); TRY(dt.alloc(sizeof(RansTable))); TRY(dres.alloc(sizeof(RansResult)));
+    HIP_TRY(hipMemcpyAsync(dh.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
+    launch_rans_table(dh.as<uint32_t>(), dt.as<RansTable>(), 1, st);
+    launch_rans_encode((const uint8_t*)d_symbols, n, n, dt.as<RansTable>(), (uint8_t*)d_out, cap, dres.as<RansResult>(), 1, st);
+    RansResult res{};
+    HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (res.flags & kTableDiverges)
+        return fail(kReferenceDiverges, "a symbol whose table frequency wrapped to 0 is present: the reference encoder does not terminate on this input");
+    if (res.flags & kRansInternal) return fail(kInternal, "rANS kernel invariant violated");
+    if (res.flags & kRansOverflow) return fail(kInvalidBufferSize, "stream region too small for this chain (use alice_codec_rans_stream_bound(NULL, n))");
+    *out_len = res.len;
+    *out_offset = cap - res.len;
+    return kOk;
+}
+
+int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32_t hist[256], void* d_symbols, uint64_t n,
+                                void* hip_stream) {
+    clear_error();
+    if ((!d_stream && len) || !hist || (!d_symbols && n)) return fail(kNullArgument, "null argument");
+    if (!n) return kOk;
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    DevBuf dh, dt, ddesc, dres;
+    TRY(dh.alloc(256 * 4)); TRY(dt.alloc(sizeof(RansTable))); TRY(ddesc.alloc(sizeof(RansDecodeDesc))); TRY(dres.alloc(sizeof(RansResult)));
+    HIP_TRY(hipMemcpyAsync(dh.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
+    RansDecodeDesc desc{(const uint8_t*)d_stream, len, (uint8_t*)d_symbols, n, dt.as<RansTable>()};
+    HIP_TRY(hipMemcpyAsync(ddesc.p, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    launch_rans_table(dh.as<uint32_t>(), dt.as<RansTable>(), 1, st);
+    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 1, st);
+    RansResult res{};
+    HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (res.flags & kRansInternal) return fail(kInternal, "rANS decode table invariant violated");
+    return kOk;
+}
+
 }  // extern "C"

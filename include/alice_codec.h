@@ -171,6 +171,32 @@ int alice_codec_rans_decode(const uint8_t *bytes, uint64_t len, const uint16_t c
 int alice_codec_rgb_to_ycocg_r(const uint8_t *rgb, uint64_t rgb_len, int16_t *y, int16_t *co, int16_t *cg, uint64_t n_out);
 int alice_codec_ycocg_r_to_rgb(const int16_t *y, const int16_t *co, const int16_t *cg, uint64_t n, uint8_t *rgb, uint64_t rgb_len);
 
+/* ---- device-resident stage calls: the pieces of FrameEncoder::encode / FrameDecoder::decode
+ * (src/pipeline.rs:429-497, 581-623) on device pointers, for callers that split ONE chunk across GPUs
+ * (row slabs) and run the exchanges between the pieces themselves.
+ * d_* are device pointers; work runs on hip_stream (hipStream_t, NULL = default) and has finished on return. ---- */
+/* colour + pad + Wavelet3D::forward + Quantizer(step(quality), dead zone = step) + to_symbols
+ * (src/pipeline.rs:429-470) of a width x height x frames RGB volume -> 3 * padded u8 symbols (Y, Co, Cg; each
+ * [pf][ph][pw], low|high halves along every axis).  d_hist: 3*256 u32 or NULL. */
+int alice_codec_dev_forward_symbols(const void *d_rgb, uint32_t width, uint32_t height, uint32_t frames,
+                                    uint8_t wavelet_type, uint8_t quality, void *d_symbols, void *d_hist,
+                                    void *hip_stream);
+/* from_symbols + dequantise (steps as stored in the chunk header) + Wavelet3D::inverse + strip + colour
+ * (src/pipeline.rs:597-621) */
+int alice_codec_dev_inverse_symbols(const void *d_symbols, uint32_t width, uint32_t height, uint32_t frames,
+                                    uint8_t wavelet_type, const int32_t step[3], void *d_rgb, void *hip_stream);
+/* build_histogram (src/quant.rs:587-600) of n device symbols -> d_hist[256] (u32, device) */
+int alice_codec_dev_histogram(const void *d_symbols, uint64_t n, void *d_hist, void *hip_stream);
+/* capacity that alice_codec_dev_rans_encode needs for n symbols with this histogram (NULL: worst case) */
+uint64_t alice_codec_rans_stream_bound(const uint32_t hist[256], uint64_t n);
+/* FrequencyTable::from_histogram(hist) + RansEncoder over n device symbols (src/pipeline.rs:479-484): the
+ * stream is written at the END of [d_out, d_out + cap): bytes [*out_offset, *out_offset + *out_len). */
+int alice_codec_dev_rans_encode(const void *d_symbols, uint64_t n, const uint32_t hist[256], void *d_out,
+                                uint64_t cap, uint64_t *out_offset, uint64_t *out_len, void *hip_stream);
+/* RansDecoder::new(stream).decode_n(n, from_histogram(hist)) (src/pipeline.rs:585-594) into device memory */
+int alice_codec_dev_rans_decode(const void *d_stream, uint64_t len, const uint32_t hist[256], void *d_symbols,
+                                uint64_t n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

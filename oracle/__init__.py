@@ -142,6 +142,15 @@ def lib(so_path: str | None = None):
         return _lib
 
 
+def _copy_out(ptr, n: int) -> np.ndarray:
+    """Copies n bytes at a C pointer into a fresh array.  (ctypes.string_at takes its size as a C int on this
+    Python, which silently truncates buffers of 2 GiB and more.)"""
+    if n == 0:
+        return np.zeros(0, np.uint8)
+    addr = C.cast(ptr, C.c_void_p).value
+    return np.frombuffer((C.c_uint8 * n).from_address(addr), dtype=np.uint8).copy()
+
+
 def _u8(a) -> np.ndarray:
     return np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray, memoryview)) else a, dtype=np.uint8)
 
@@ -157,7 +166,7 @@ def _check(rc: int):
 
 def _take(pp, n) -> bytes:
     try:
-        return C.string_at(pp, n) if n else b""
+        return _copy_out(pp, n).tobytes()
     finally:
         lib().ao_free(C.cast(pp, C.c_void_p))
 
@@ -336,7 +345,7 @@ def encode(rgb, width: int, height: int, frames: int, quality: int, wavelet: int
     _check(L.ao_encode(_ptr(r, _u8p), r.size, width, height, frames, quality, wavelet,
                        C.byref(out), C.byref(n)))
     try:
-        return C.string_at(out, n.value)
+        return _copy_out(out, n.value).tobytes()
     finally:
         L.ao_free(C.cast(out, C.c_void_p))
 
@@ -348,7 +357,7 @@ def decode(alc, _lib=None) -> np.ndarray:
     out = _u8p(); n = C.c_size_t()
     _check(L.ao_decode(_ptr(d, _u8p), d.size, C.byref(out), C.byref(n)))
     try:
-        return np.frombuffer(C.string_at(out, n.value), np.uint8).copy()
+        return _copy_out(out, n.value)
     finally:
         L.ao_free(C.cast(out, C.c_void_p))
 
