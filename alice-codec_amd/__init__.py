@@ -141,6 +141,7 @@ def load_library() -> C.CDLL:
         "alice_codec_batch_decode_finish": (C.c_int, [vp]),
         "alice_codec_batch_stage_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "alice_codec_batch_symbols_ptr": (vp, [vp]),
+        "alice_codec_batch_rgb_ptr": (vp, [vp, C.c_uint32]),
         "alice_codec_batch_padded_pixels": (C.c_uint64, [vp]),
         "alice_codec_wavelet2d_forward": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64]),
         "alice_codec_wavelet2d_inverse": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64]),
@@ -677,7 +678,8 @@ class Batch:
         sizes = np.ascontiguousarray(sizes, np.uint64)
         _check(load_library().alice_codec_batch_pack_alc(self._h, _p(sizes, _u64p), d_dst_ptr, dst_capacity, stream))
 
-    def decode(self, d_alc_ptr: int, alc_stride: int, d_rgb_out_ptr: int, stream: int = 0) -> None:
+    def decode(self, d_alc_ptr: int, alc_stride: int, d_rgb_out_ptr: int | None, stream: int = 0) -> None:
+        """d_rgb_out_ptr None: decode into the batch's own storage, read the pixels at rgb_ptr(chunk)."""
         _check(load_library().alice_codec_batch_decode(self._h, d_alc_ptr, alc_stride, d_rgb_out_ptr, stream))
 
     def decode_finish(self) -> None:
@@ -688,6 +690,9 @@ class Batch:
         load_library().alice_codec_batch_stage_ms(self._h, out)
         keys = ["forward_transform", "rans_table", "rans_encode", "assemble", "rans_decode", "inverse_transform"]
         return dict(zip(keys, [float(v) for v in out]))
+
+    def rgb_ptr(self, chunk: int = 0) -> int:
+        return load_library().alice_codec_batch_rgb_ptr(self._h, chunk)
 
     def symbols_ptr(self) -> int:
         return load_library().alice_codec_batch_symbols_ptr(self._h)

@@ -500,8 +500,9 @@ int inverse_generic(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const
 }
 
 // headers[b]: parsed chunk headers (validated); d_payload[b]: device pointer to chunk b's payload
+// rgb_stride: bytes between the outputs of consecutive chunks (0 = packed, n_pixels * 3)
 int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<const uint8_t*>& d_payload,
-                  DecodeWork& w, uint8_t* d_rgb_out, hipStream_t st, StageEvents* evs) {
+                  DecodeWork& w, uint8_t* d_rgb_out, hipStream_t st, StageEvents* evs, uint64_t rgb_stride = 0) {
     const ChunkDims& d = w.d;
     const int B = w.n_chunks;
     std::vector<uint32_t> hist((size_t)B * 3 * 256);
@@ -531,7 +532,7 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
         int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
         const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
         const uint8_t* sym = w.sym_ptr + (size_t)b * 3 * d.padded;
-        uint8_t* rgb = d_rgb_out + (size_t)b * d.n_pixels * 3;
+        uint8_t* rgb = d_rgb_out + (size_t)b * (rgb_stride ? rgb_stride : d.n_pixels * 3);
         if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, w.mid_ptr, rgb, st))
             TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, rgb, st));
     }
@@ -940,7 +941,7 @@ int alice_codec_batch_pack_alc(AliceBatch* b, const uint64_t* sizes, void* d_dst
 
 int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stride, void* d_rgb_out, void* hip_stream) {
     clear_error();
-    if (!b || !d_alc || !d_rgb_out) return fail(kNullArgument, "null argument");
+    if (!b || !d_alc) return fail(kNullArgument, "null argument");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
     b->dec_stream = st;
@@ -965,7 +966,15 @@ int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stri
         TRY(validate_for_decode(headers[i], &dd, payload));
         pay[i] = (const uint8_t*)d_alc + (size_t)i * alc_stride + kAlcHeaderBytes;
     }
+    // d_rgb_out == NULL: every chunk is reconstructed over its own (by then consumed) symbols, see
+    // alice_codec_batch_rgb_ptr; the temporal pass of chunk i is the last reader of those symbols and runs
+    // before the tile pass that writes the pixels.
+    if (!d_rgb_out) return decode_launch(headers, pay, b->dec, b->dec.sym_ptr, st, &b->evs, 3 * b->d.padded);
     return decode_launch(headers, pay, b->dec, (uint8_t*)d_rgb_out, st, &b->evs);
+}
+const void* alice_codec_batch_rgb_ptr(const AliceBatch* b, uint32_t chunk) {
+    if (!b || chunk >= b->n_chunks) return nullptr;
+    return b->enc.sym.as<uint8_t>() + (size_t)chunk * 3 * b->d.padded;
 }
 int alice_codec_batch_decode_finish(AliceBatch* b) {
     clear_error();

@@ -6,7 +6,7 @@ Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) with device te
 GPU box, "gloo" with CPU tensors in the CPU test-suite."""
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -36,8 +36,10 @@ def gather_alc(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
     return gather_alc_start(packed, sizes, dst, group).wait()
 
 
-def gather_alc_start(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
-                     group: Optional[dist.ProcessGroup] = None, blob: Optional[torch.Tensor] = None) -> PendingGather:
+def gather_alc_start(packed: Optional[torch.Tensor], sizes: torch.Tensor, dst: int = 0,
+                     group: Optional[dist.ProcessGroup] = None, blob: Optional[torch.Tensor] = None,
+                     pack_fn: Optional[Callable[[torch.Tensor], None]] = None,
+                     device: Optional[torch.device] = None) -> PendingGather:
     """Variable-length gather of per-rank `.alc` blobs.
 
     packed: uint8 tensor holding this rank's chunks back to back (only the first sizes.sum() bytes count).
@@ -46,10 +48,13 @@ def gather_alc_start(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
     all_sizes of shape [world, chunks_per_rank]; None elsewhere.
     One small all_gather (lengths) plus one point-to-point transfer per peer: a fan-in on the
     root's links, no ring.  The transfers are left in flight (RCCL runs them on its own stream) so the
-    caller can overlap them with the decode; `blob` lets the root reuse its receive buffer across steps."""
+    caller can overlap them with the decode; `blob` lets the root reuse its receive buffer across steps.
+    pack_fn (root only): writes the root's own bytes straight into its slice of the blob, so that the root
+    needs no `packed` staging buffer of its own (pass packed=None and `device`)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    sizes = sizes.to(packed.device, torch.int64)
+    dev = packed.device if packed is not None else torch.device(device)
+    sizes = sizes.to(dev, torch.int64)
     all_sizes = [torch.empty_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes_t = torch.stack(all_sizes)
@@ -58,12 +63,15 @@ def gather_alc_start(packed: torch.Tensor, sizes: torch.Tensor, dst: int = 0,
     if rank == dst:
         need = int(sum(totals))
         if blob is None or blob.numel() < need:
-            blob = torch.empty(need, dtype=torch.uint8, device=packed.device)
+            blob = torch.empty(need, dtype=torch.uint8, device=dev)
         blob = blob[:need]
         offs = [0]
         for t in totals:
             offs.append(offs[-1] + int(t))
-        blob[offs[rank]:offs[rank] + mine].copy_(packed[:mine])
+        if pack_fn is not None:
+            pack_fn(blob[offs[rank]:offs[rank] + mine])
+        else:
+            blob[offs[rank]:offs[rank] + mine].copy_(packed[:mine])
         ops = []
         for r in range(world):
             if r != dst and totals[r] > 0:

@@ -98,8 +98,10 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "96")),
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "128")),
                     help="1080p x 64 chunks in flight per GPU (3 rANS chains each)")
+    ap.add_argument("--separate-output", action="store_true",
+                    help="decode into a caller-owned RGB buffer instead of the batch's own storage (one more RGB-sized buffer per chunk)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of chunk 0 in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main() -> None:
     rgb = torch.empty((B, F, H, W, 3), dtype=torch.uint8, device=dev)
     for i in range(B):
         rgb[i] = synth_chunk(dev, rank * B + i)
-    out = torch.empty_like(rgb)
+    out = torch.empty_like(rgb) if args.separate_output else None
     batch = ac.Batch(W, H, F, B, QUALITY, WAVELET)
     stream = torch.cuda.current_stream().cuda_stream
     packed = None
@@ -141,11 +143,16 @@ def main() -> None:
         pending = None
         if use_dist:
             # the gather of the finished .alc blobs on rank 0 runs on RCCL's stream beside the decode
-            if packed is None:
-                packed = torch.empty(int(sizes.sum()) + 4096, dtype=torch.uint8, device=dev)
-            batch.pack_alc(sizes, packed.data_ptr(), packed.numel(), stream)
-            pending = multi.gather_alc_start(packed, torch.from_numpy(sizes.astype(np.int64)), blob=blob)
-        batch.decode(batch.alc_ptr(0), batch.alc_stride, out.data_ptr(), stream)
+            # (the root packs its own chunks straight into its slice of the gathered blob)
+            if rank == 0:
+                pending = multi.gather_alc_start(None, torch.from_numpy(sizes.astype(np.int64)), blob=blob, device=dev,
+                                                 pack_fn=lambda dst: batch.pack_alc(sizes, dst.data_ptr(), dst.numel(), stream))
+            else:
+                if packed is None:
+                    packed = torch.empty(int(sizes.sum()) + 4096, dtype=torch.uint8, device=dev)
+                batch.pack_alc(sizes, packed.data_ptr(), packed.numel(), stream)
+                pending = multi.gather_alc_start(packed, torch.from_numpy(sizes.astype(np.int64)), blob=blob)
+        batch.decode(batch.alc_ptr(0), batch.alc_stride, out.data_ptr() if out is not None else None, stream)
         batch.decode_finish()
         if pending is not None:
             res = pending.wait()

@@ -124,9 +124,13 @@ uint64_t alice_codec_batch_alc_stride(const AliceBatch *batch); /* valid after a
 int alice_codec_batch_pack_alc(AliceBatch *batch, const uint64_t *sizes, void *d_dst, uint64_t dst_capacity,
                                void *hip_stream);
 /* d_alc: device pointer, chunk i at d_alc + i*alc_stride (whole .alc, header first).
- * d_rgb_out: device pointer to n_chunks * width*height*frames*3 bytes. Synchronises once to read headers. */
+ * d_rgb_out: device pointer to n_chunks * width*height*frames*3 bytes, or NULL: the pixels of chunk i are then
+ * written into the batch's own storage (over the chunk's symbols, which the decode has consumed by then) and
+ * are read at alice_codec_batch_rgb_ptr(batch, i) until the next encode/decode on the batch -- saves one
+ * RGB-sized buffer per chunk in flight.  Synchronises once to read headers. */
 int alice_codec_batch_decode(AliceBatch *batch, const void *d_alc, uint64_t alc_stride, void *d_rgb_out,
                              void *hip_stream);
+const void *alice_codec_batch_rgb_ptr(const AliceBatch *batch, uint32_t chunk); /* device pointer, see above */
 int alice_codec_batch_decode_finish(AliceBatch *batch);
 /* per-stage device times of the last encode+finish / decode+finish, measured with HIP events on the
  * batch's stream: [0] forward transform, [1] table, [2] rANS encode, [3] assemble,

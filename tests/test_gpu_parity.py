@@ -375,6 +375,35 @@ def test_batch_matches_single_chunk_path(gpu_codec, oracle_mod):
         assert np.array_equal(got[i], oracle_mod.decode(host[i])), i
     ms = bt.stage_ms()
     assert ms["rans_encode"] > 0 and ms["rans_decode"] > 0
+    # in-place form (what bench.py runs): pixels of chunk i land over the chunk's consumed symbols
+    bt.decode(bt.alc_ptr(0), stride, None, st)
+    bt.decode_finish()
+    for i in range(B):
+        t = torch.empty(w * h * f * 3, dtype=torch.uint8, device="cuda")
+        gpu_hip_memcpy(t.data_ptr(), bt.rgb_ptr(i), t.numel())
+        assert np.array_equal(t.cpu().numpy(), got[i].reshape(-1)), i
+    # and the batch is reusable afterwards
+    bt.encode(rgb.data_ptr(), st)
+    assert np.array_equal(bt.encode_finish(), sizes)
+
+
+def test_batch_in_place_decode_odd_shape(gpu_codec, oracle_mod):
+    """padded != real size: the in-place outputs sit at a stride of 3 * padded bytes"""
+    import torch
+    w, h, f, B = 45, 31, 5, 3
+    chunks = [smooth_rgb(w, h, f, seed=300 + i, shift=i) for i in range(B)]
+    rgb = torch.from_numpy(np.stack(chunks)).cuda()
+    bt = gpu_codec.Batch(w, h, f, B, 90, gpu_codec.WaveletType.Cdf97)
+    st = torch.cuda.current_stream().cuda_stream
+    bt.encode(rgb.data_ptr(), st)
+    sizes = bt.encode_finish()
+    bt.decode(bt.alc_ptr(0), bt.alc_stride, None, st)
+    bt.decode_finish()
+    for i in range(B):
+        t = torch.empty(w * h * f * 3, dtype=torch.uint8, device="cuda")
+        gpu_hip_memcpy(t.data_ptr(), bt.rgb_ptr(i), t.numel())
+        want = oracle_mod.decode(oracle_mod.encode(chunks[i], w, h, f, 90, 1))
+        assert np.array_equal(t.cpu().numpy(), want), i
 
 
 def gpu_hip_memcpy(dst, src, n):
