@@ -40,8 +40,13 @@ __device__ __forceinline__ int lift_delta(int a, int b, int c) {
         return (int)(((long long)avg * (long long)c + 4096ll) >> 13);
     } else {
         // callers guarantee |a + b| < 2^23 and |(a + b) * c| < 2^31 (forward: u8 input; inverse: host bound
-        // check), so the full-rate 24-bit multiply-add is exact
-        return (__mul24(a + b, c) + 4096) >> 13;
+        // check), so the full-rate 24-bit multiply-add is exact.  Written as asm because the compiler, once it
+        // has proven the operand ranges, rewrites __mul24 into a generic multiply and then selects the
+        // quarter-rate v_mul_lo_u32 for a third of the products (seen in the ISA of every kernel here).
+        int m;
+        const int rnd = 4096;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(m) : "v"(a + b), "s"(c), "v"(rnd));
+        return m >> 13;
     }
 }
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -61,6 +66,22 @@ __device__ __forceinline__ unsigned xcd_logical_block(unsigned total) {
     return l < total ? l : 0xFFFFFFFFu;
 }
 static inline unsigned xcd_grid(unsigned long long total) { return (unsigned)(((total + 7) / 8) * 8); }
+
+// Whole-sample symmetric extension of an even-length signal: x[-k] = x[k], x[n-1+k] = x[n-1-k].
+// The reference mirrors one neighbour at the two ends of every lifting step (src/wavelet.rs:186-190,
+// 206-210: the last odd sample predicts from its left neighbour twice, the first even sample updates from
+// its right neighbour twice).  That is exactly what plain lifting computes on the symmetric extension:
+// the extension is symmetric about an even sample on the left and an odd sample on the right, and every
+// predict/update step maps such a signal to one with the same symmetry.  So a tile that LOADS through this
+// index map needs no boundary logic in its arithmetic, and parity (low/high band) is preserved.
+// One reflection is exact for every position within the halo (|distance| <= 4) of a signal of length >= 6
+// (the launchers send shorter ones to the generic path); positions further out belong to tiles that overhang
+// the frame, whose results are never stored: they only need a valid address, hence the clamp.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    int r = i < 0 ? -i : i;
+    r = r >= n ? 2 * (n - 1) - r : r;
+    return min(max(r, 0), n - 1);
+}
 
 // ------------------------------------------------------------------------------------------------
 // In-register 1-D lifting of N consecutive samples (v[0] has even global index g0).
@@ -135,8 +156,10 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
     if (tid < ER * F_NSEG) {
         const int r = tid >> 3, s = tid & 7;
         const int gy = gy0 - H + r;
-        if (!EDGE || (gy >= 0 && gy < ph)) {
-            const int sy = EDGE ? min(gy, (int)d.h - 1) : gy;
+        {
+            // border tiles read through the symmetric extension (rows and columns), then the pad row/column
+            // of an odd size (src/pipeline.rs:77-114: edge replicate) clamps to the last real one
+            const int sy = EDGE ? min(reflect_idx(gy, ph), (int)d.h - 1) : gy;
             const int gxs = gx0 - 4 + s * F_SEG;
             const uint8_t* row = rgb + ((size_t)st * d.h + sy) * d.w * 3;
             int y[SE], co[SE], cg[SE];
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
 #pragma unroll
                 for (int k = 0; k < SE; ++k) {
                     const int gx = gxs + k;
-                    const int sx = min(max(gx, 0), (int)d.w - 1);
+                    const int sx = EDGE ? min(reflect_idx(gx, pw), (int)d.w - 1) : gx;
                     const uint8_t* p = row + (size_t)sx * 3;
                     const int rr = p[0], gg = p[1], bb = p[2];
                     const int c_o = rr - bb;
@@ -172,10 +195,9 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             int ly[NL], lco[NL], lcg[NL];
 #pragma unroll
             for (int k = 0; k < NL; ++k) { ly[k] = y[K0 + k]; lco[k] = co[K0 + k]; lcg[k] = cg[K0 + k]; }
-            const int g0 = gxs + K0;
-            lift_regs<NL, NS, EDGE, false, false>(ly, cf, g0, pw);
-            lift_regs<NL, NS, EDGE, false, false>(lco, cf, g0, pw);
-            lift_regs<NL, NS, EDGE, false, false>(lcg, cf, g0, pw);
+            lift_regs<NL, NS, false, false, false>(ly, cf, 0, 0);
+            lift_regs<NL, NS, false, false, false>(lco, cf, 0, 0);
+            lift_regs<NL, NS, false, false, false>(lcg, cf, 0, 0);
             // interior 16 samples -> LDS row r as packed i16 pairs (values stay below 2^13 after the row pass):
             // dword q of a row holds deinterleaved positions (2q, 2q+1); evens of segment s start at
             // position s*8, odds at 64 + s*8
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             const int sh = (xq & 1) * 16;
 #pragma unroll
             for (int r = 0; r < ER; ++r) v[r] = (int)(short)(L[r * F_LP] >> sh);
-            lift_regs<ER, NS, EDGE, false, false>(v, cf, gy0 - H, ph);
+            lift_regs<ER, NS, false, false, false>(v, cf, 0, 0);
             int16_t* out = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
 #pragma unroll
             for (int k = 0; k < F_TH; ++k) {
@@ -240,129 +262,186 @@ __device__ __forceinline__ I4 lift4(const I4& base, const I4& a, const I4& b, in
     return r;
 }
 
-// Histogram bins in LDS: 8 replicas of the 256 bins (replica = lane & 7) cut same-address atomics
-// eightfold; a zero symbol (45-90 % of the data) goes to a slot private to its thread instead, so the
-// add is unconditional (no exec-mask branch) and conflict-free.  Zeros are recovered as total - nonzero.
-constexpr int kHistReplicas = 8;
-constexpr int kHistWords = kHistReplicas * 256 + 256;
+// Histogram bins in LDS: 32 replicas of the 256 bins, word index = symbol * 32 + (lane & 31).  The replica is
+// the bank, so one ds_add is conflict-free up to the two half-waves; the dominant zero symbol (45-90 % of the
+// data) spreads over 32 addresses instead of serialising on one.
+constexpr int kHistReplicas = 32;
+constexpr int kHistWords = kHistReplicas * 256;
+
+__device__ __forceinline__ uint32_t sat_sub_u32(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
 
 // Quantizer::quantize (src/quant.rs:89-97, dead zone = step) followed by to_symbols (:555-560), branch-free:
 //   q = (|v| - step/2) / step for |v| >= step, else 0.  For |v| < step the quotient of the saturating
 //   difference is already 0, so the dead-zone test disappears; symbol = 2q - (v > 0), and the one case that
-//   would go negative (q = 0, v > 0) is exactly the case to_symbols maps to 0.
+//   would go negative (q = 0, v > 0; also v = 0 in the form used below) is exactly the case to_symbols maps to 0
+//   (second saturating subtract).
 template <bool STEP1, bool HIST>
-__device__ __forceinline__ uint32_t quant_sym4(const I4& x, int hdz, uint32_t magic, uint32_t* lh, int rep_base, int dummy) {
-    uint32_t packed = 0u;
+__device__ __forceinline__ uint32_t quant_sym4(const I4& x, uint32_t hdz, uint32_t magic, uint32_t* lh, uint32_t lane_rep) {
+    uint32_t s[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int val = x.v[i];
         const int neg = -val;
         const uint32_t mag = (uint32_t)max(val, neg);
-        const uint32_t adj = mag > (uint32_t)hdz ? mag - (uint32_t)hdz : 0u;      // saturating
+        const uint32_t adj = sat_sub_u32(mag, hdz);
         const uint32_t q = STEP1 ? adj : __umulhi(adj, magic);                     // exact: adj * step < 2^32
-        const int t = (int)(q << 1) + (neg >> 31);                                 // 2q - (v > 0)
-        const uint32_t s = (uint32_t)max(t, 0) & 0xFFu;                            // `as u8`
-        if (HIST) atomicAdd(&lh[s ? (rep_base + (int)s) : dummy], 1u);
-        packed |= s << (8 * i);
+        // 2q - (v > 0) with floor 0, as 2q + (v < 0) - 1 saturating: v < 0 -> 2q, v > 0 -> 2q - 1, v = 0 -> 0
+        const uint32_t t = sat_sub_u32((q << 1) + ((uint32_t)val >> 31), 1u);
+        s[i] = t & 0xFFu;                                                          // `as u8`
+        if (HIST) atomicAdd(&lh[(s[i] << 5) + lane_rep], 1u);
     }
-    return packed;
+    return s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
 }
+
+__device__ __forceinline__ I4 unpack4_i16(const uint2 w) {
+    I4 r;
+    r.v[0] = (int)(short)(w.x & 0xFFFF); r.v[1] = (int)w.x >> 16;
+    r.v[2] = (int)(short)(w.y & 0xFFFF); r.v[3] = (int)w.y >> 16;
+    return r;
+}
+
+// Temporal lifting as a stream over frame pairs k = 0 .. half-1 (E0[k], O0[k] = frames 2k, 2k+1 of one pixel):
+//   P1: O1[k] = O0[k] + d(E0[k], E0[k+1])      (E0[half] := E0[half-1], src/wavelet.rs:186-190)
+//   U1: E1[k] = E0[k] + d(O1[k-1], O1[k])      (O1[-1]   := O1[0],      :206-210)
+//   P2: O2[k] = O1[k] + d(E1[k], E1[k+1])      U2: E2[k] = E1[k] + d(O2[k-1], O2[k])     (CDF 9/7 only)
+// Tick k consumes pair k (and E0[k+1]) and emits E2[k-1] -> frame k-1, O2[k-1] -> frame half+k-1; the state
+// between ticks is O1[k], E1[k], O2[k-1] plus the raw pairs in flight: five values per pixel.
+// The tick is instantiated per position in a 4-tick block so that every register role is static: no window
+// shuffling moves, no per-tick selects except the end-of-signal mirror.
+template <int NS, bool STEP1, bool HIST>
+struct FwdT {
+    const char* src;     // channel base (uniform)
+    char* dst;
+    size_t plane;
+    uint32_t off16, off8;  // this thread's byte offset inside an i16 / u8 frame
+    int half;
+    Coeffs cf;
+    uint32_t hdz, magic, lane_rep;
+    uint32_t* lh;
+    I4 o1p, e1p, o2pp;
+
+    __device__ __forceinline__ void load_pair(int pair, uint2& e, uint2& o) const {
+        const char* fe = src + (size_t)(2 * pair) * plane * 2;
+        e = *(const uint2*)(fe + off16);
+        o = *(const uint2*)(fe + plane * 2 + off16);
+    }
+    __device__ __forceinline__ void emit(int frame, const I4& lo, const I4& hi) const {
+        const uint32_t a = quant_sym4<STEP1, HIST>(lo, hdz, magic, lh, lane_rep);
+        const uint32_t b = quant_sym4<STEP1, HIST>(hi, hdz, magic, lh, lane_rep);
+        *(uint32_t*)(dst + (size_t)frame * plane + off8) = a;
+        *(uint32_t*)(dst + (size_t)(half + frame) * plane + off8) = b;
+    }
+    // FIRST: k == 0, SECOND: k == 1 (the left mirrors); en = E0[k+1] or, on the last pair, E0[k] itself
+    template <bool FIRST, bool SECOND>
+    __device__ __forceinline__ void tick(int k, const I4& ce, const I4& co, const I4& en) {
+        const I4 o1 = lift4<false>(co, ce, en, cf.c[0]);
+        const I4 e1 = lift4<false>(ce, FIRST ? o1 : o1p, o1, cf.c[1]);
+        if (NS == 2) {
+            emit(k, e1, o1);
+        } else if (!FIRST) {
+            const I4 o2 = lift4<false>(o1p, e1p, e1, cf.c[2]);
+            const I4 e2 = lift4<false>(e1p, SECOND ? o2 : o2pp, o2, cf.c[3]);
+            emit(k - 1, e2, o2);
+            o2pp = o2;
+        }
+        o1p = o1; e1p = e1;
+    }
+    // after the last pair: E1[half] := E1[half-1]
+    __device__ __forceinline__ void flush() {
+        if (NS == 2) return;
+        const I4 o2 = lift4<false>(o1p, e1p, e1p, cf.c[2]);
+        const I4 e2 = lift4<false>(e1p, half == 1 ? o2 : o2pp, o2, cf.c[3]);
+        emit(half - 1, e2, o2);
+    }
+};
 
 template <int NS, bool STEP1, bool HIST>
 __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ mid, uint8_t* __restrict__ sym,
                                                     uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf, int step,
                                                     uint32_t magic) {
-    __shared__ uint32_t lh[kHistWords];
+    __shared__ uint32_t lh[HIST ? kHistWords : 1];
     const int tid = threadIdx.x;
-    for (int i = tid; i < kHistWords; i += 256) lh[i] = 0u;
-    __syncthreads();
+    if (HIST) {
+        for (int i = tid; i < kHistWords; i += 256) lh[i] = 0u;
+        __syncthreads();
+    }
     const size_t plane = (size_t)d.pw * d.ph;
     const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
     const int ch = blockIdx.y;
-    const int pf = d.pf, half = pf / 2;
-    const int rep_base = (tid & (kHistReplicas - 1)) * 256, dummy = kHistReplicas * 256 + tid;
-    const int hdz = step / 2;
-    uint32_t emitted = 0u;
+    const int half = (int)d.pf / 2;
     if (idx < plane) {
-        emitted = 4u * (uint32_t)pf;
-        const int16_t* src = mid + (size_t)ch * pf * plane + idx;
-        uint32_t* dst = (uint32_t*)(sym + (size_t)ch * pf * plane + idx);
-        const size_t plane4 = plane / 4;
-        // window: raw pair j-1, O1[j-2], E1[j-2], O2[j-3] (9/7); see the derivation in DESIGN.md
-        I4 e0p{}, o0p{}, o1pp{}, e1pp{}, o2ppp{};
-        I4 e0c = load4_i16(src), o0c = load4_i16(src + plane);
-        I4 e0n{}, o0n{};
-        if (1 < half) { e0n = load4_i16(src + (size_t)2 * plane); o0n = load4_i16(src + (size_t)3 * plane); }
-        const int last = (NS == 4) ? half + 1 : half;
-#pragma unroll 2
-        for (int j = 0; j <= last; ++j) {
-            I4 e0nn{}, o0nn{};
-            if (j + 2 < half) {  // prefetch pair j+2
-                e0nn = load4_i16(src + (size_t)(2 * j + 4) * plane);
-                o0nn = load4_i16(src + (size_t)(2 * j + 5) * plane);
+        FwdT<NS, STEP1, HIST> f;
+        f.src = (const char*)(mid + (size_t)ch * d.pf * plane);
+        f.dst = (char*)(sym + (size_t)ch * d.pf * plane);
+        f.plane = plane; f.off16 = (uint32_t)idx * 2u; f.off8 = (uint32_t)idx;
+        f.half = half; f.cf = cf; f.hdz = (uint32_t)step / 2u; f.magic = magic; f.lane_rep = (uint32_t)tid & 31u; f.lh = lh;
+        f.o1p = I4{}; f.e1p = I4{}; f.o2pp = I4{};
+        uint2 re[4], ro[4];   // raw pairs in flight; slot = pair & 3, always a compile-time index below
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { re[i] = make_uint2(0u, 0u); ro[i] = make_uint2(0u, 0u); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < half) f.load_pair(i, re[i], ro[i]);
+        I4 ce = unpack4_i16(re[0]), co = unpack4_i16(ro[0]);
+        // block 0: the two left mirrors are static; block ends may fall anywhere (short signals)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < half) {
+                if (u + 3 < half) f.load_pair(u + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
+                const I4 ne = unpack4_i16(re[(u + 1) & 3]);
+                const bool last = u == half - 1;
+                I4 en;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) en.v[i] = last ? ce.v[i] : ne.v[i];
+                if (u == 0) f.template tick<true, false>(u, ce, co, en);
+                else if (u == 1) f.template tick<false, true>(u, ce, co, en);
+                else f.template tick<false, false>(u, ce, co, en);
+                ce = ne; co = unpack4_i16(ro[(u + 1) & 3]);
             }
-            if (j >= 1) {
-                I4 o1p, e1p;
-                bool have1 = j <= half;
-                if (have1) {
-                    // P1 for pair j-1: right neighbour is E0[j] or (at the end) E0[j-1] itself
-                    o1p = lift4<false>(o0p, e0p, (j < half) ? e0c : e0p, cf.c[0]);
-                    // U1 for pair j-1: left neighbour is O1[j-2] or (at the start) O1[0]
-                    e1p = lift4<false>(e0p, (j >= 2) ? o1pp : o1p, o1p, cf.c[1]);
-                }
-                if (NS == 2) {
-                    const uint32_t lo = quant_sym4<STEP1, HIST>(e1p, hdz, magic, lh, rep_base, dummy);
-                    const uint32_t hi = quant_sym4<STEP1, HIST>(o1p, hdz, magic, lh, rep_base, dummy);
-                    dst[(size_t)(j - 1) * plane4] = lo;
-                    dst[(size_t)(half + j - 1) * plane4] = hi;
-                } else {
-                    if (j >= 2) {
-                        // P2 for pair j-2: right neighbour E1[j-1] or mirror E1[j-2]
-                        const I4 o2pp = lift4<false>(o1pp, e1pp, have1 ? e1p : e1pp, cf.c[2]);
-                        // U2 for pair j-2: left neighbour O2[j-3] or mirror O2[0]
-                        const I4 e2pp = lift4<false>(e1pp, (j >= 3) ? o2ppp : o2pp, o2pp, cf.c[3]);
-                        const uint32_t lo = quant_sym4<STEP1, HIST>(e2pp, hdz, magic, lh, rep_base, dummy);
-                        const uint32_t hi = quant_sym4<STEP1, HIST>(o2pp, hdz, magic, lh, rep_base, dummy);
-                        dst[(size_t)(j - 2) * plane4] = lo;
-                        dst[(size_t)(half + j - 2) * plane4] = hi;
-                        o2ppp = o2pp;
-                    }
-                }
-                if (have1) { o1pp = o1p; e1pp = e1p; }
-            }
-            e0p = e0c; o0p = o0c;
-            e0c = e0n; o0c = o0n;
-            e0n = e0nn; o0n = o0nn;
         }
+        // steady state: whole blocks strictly before the last pair
+        int kb = 4;
+        for (; kb + 4 <= half - 1; kb += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u;
+                if (k + 3 < half) f.load_pair(k + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
+                const I4 ne = unpack4_i16(re[(u + 1) & 3]);
+                f.template tick<false, false>(k, ce, co, ne);
+                ce = ne; co = unpack4_i16(ro[(u + 1) & 3]);
+            }
+        }
+        // tail: up to 4 + 3 remaining pairs, the last one mirrors
+        for (; kb < half; kb += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u;
+                if (k < half) {
+                    if (k + 3 < half) f.load_pair(k + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
+                    const I4 ne = unpack4_i16(re[(u + 1) & 3]);
+                    const bool last = k == half - 1;
+                    I4 en;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) en.v[i] = last ? ce.v[i] : ne.v[i];
+                    f.template tick<false, false>(k, ce, co, en);
+                    ce = ne; co = unpack4_i16(ro[(u + 1) & 3]);
+                }
+            }
+        }
+        f.flush();
     }
     if (!HIST) return;
     __syncthreads();
-    // fold the replicas; bin 0 = symbols emitted by this block - nonzero symbols
-    __shared__ uint32_t tot_sh, nz_sh;
-    if (tid == 0) { tot_sh = 0u; nz_sh = 0u; }
-    __syncthreads();
+    // fold the replicas of bin `tid` (rotated start: the 256 threads read 32 different banks)
     uint32_t cnt = 0u;
-#pragma unroll
-    for (int r = 0; r < kHistReplicas; ++r) cnt += lh[r * 256 + tid];
-    if (emitted) atomicAdd(&tot_sh, emitted);
-    if (tid != 0 && cnt) { atomicAdd(&nz_sh, cnt); atomicAdd(&hist[ch * 256 + tid], cnt); }
-    __syncthreads();
-    if (tid == 0 && tot_sh > nz_sh) atomicAdd(&hist[ch * 256], tot_sh - nz_sh);
+#pragma unroll 8
+    for (int r = 0; r < kHistReplicas; ++r) cnt += lh[tid * kHistReplicas + ((r + tid) & (kHistReplicas - 1))];
+    if (cnt) atomicAdd(&hist[ch * 256 + tid], cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: from_symbols + dequantize + inverse temporal lifting (stream over pairs); frames t < f only
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ I4 dequant4(uint32_t packed, int step) {
-    I4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = (packed >> (8 * i)) & 0xFF;
-        const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));  // src/quant.rs:581-587
-        r.v[i] = (int)((unsigned)q * (unsigned)step);                      // src/quant.rs:104-110
-    }
-    return r;
-}
 template <typename MidT>
 __device__ __forceinline__ void store4(MidT* p, const I4& x);
 template <>
@@ -377,63 +456,124 @@ __device__ __forceinline__ void store4<int16_t>(int16_t* p, const I4& x) {
     *(uint2*)p = w;
 }
 
+// Inverse stream (steps reversed with negated coefficients, src/wavelet.rs:167-174):
+//   U2': E1[k] = E2[k] + d(O2[k-1], O2[k])     P2': O1[k] = O2[k] + d(E1[k], E1[k+1])
+//   U1': E0[k] = E1[k] + d(O1[k-1], O1[k])     P1': O0[k] = O1[k] + d(E0[k], E0[k+1])
+// Tick k consumes the symbols of frames k (low band) and half+k (high band), emits frame 2(k-1) and
+// frame 2(k-2)+1.  from_symbols + dequantize (src/quant.rs:104-110,581-587) is a 256-entry table in LDS:
+// one byte extract and one LDS read per sample instead of seven VALU operations.
+template <int NS, bool EXACT, typename MidT>
+struct InvT {
+    const char* src;
+    MidT* dst;            // channel base + this thread's pixel offset
+    size_t plane;
+    uint32_t off8;
+    int half, nf;
+    int c0, c1, c2, c3;   // already negated
+    const int* lut;
+    I4 o2p, e1p, o1pp, e0pp;
+
+    __device__ __forceinline__ void load_pair(int pair, uint32_t& lo, uint32_t& hi) const {
+        lo = *(const uint32_t*)(src + (size_t)pair * plane + off8);
+        hi = *(const uint32_t*)(src + (size_t)(half + pair) * plane + off8);
+    }
+    __device__ __forceinline__ I4 dq(uint32_t packed) const {
+        I4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.v[i] = lut[(packed >> (8 * i)) & 0xFFu];
+        return r;
+    }
+    __device__ __forceinline__ void put(int frame, const I4& x) const {
+        if (frame < nf) store4<MidT>(dst + (size_t)frame * plane, x);
+    }
+    template <bool FIRST, bool SECOND>
+    __device__ __forceinline__ void tick(int k, uint32_t lo, uint32_t hi) {
+        const I4 hv = dq(hi), lv = dq(lo);
+        if (NS == 4) {
+            const I4 e1 = lift4<EXACT>(lv, FIRST ? hv : o2p, hv, c3);
+            if (!FIRST) {
+                const I4 o1 = lift4<EXACT>(o2p, e1p, e1, c2);
+                const I4 e0 = lift4<EXACT>(e1p, SECOND ? o1 : o1pp, o1, c1);
+                put(2 * (k - 1), e0);
+                if (!SECOND) put(2 * (k - 2) + 1, lift4<EXACT>(o1pp, e0pp, e0, c0));
+                o1pp = o1; e0pp = e0;
+            }
+            o2p = hv; e1p = e1;
+        } else {
+            const I4 e0 = lift4<EXACT>(lv, FIRST ? hv : o2p, hv, c1);
+            put(2 * k, e0);
+            if (!FIRST) put(2 * (k - 1) + 1, lift4<EXACT>(o2p, e1p, e0, c0));
+            o2p = hv; e1p = e0;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (NS == 4) {
+            const I4 o1 = lift4<EXACT>(o2p, e1p, e1p, c2);
+            const I4 e0 = lift4<EXACT>(e1p, half == 1 ? o1 : o1pp, o1, c1);
+            put(2 * (half - 1), e0);
+            if (half >= 2) put(2 * (half - 2) + 1, lift4<EXACT>(o1pp, e0pp, e0, c0));
+            put(2 * (half - 1) + 1, lift4<EXACT>(o1, e0, e0, c0));
+        } else {
+            put(2 * (half - 1) + 1, lift4<EXACT>(o2p, e1p, e1p, c0));
+        }
+    }
+};
+
 template <int NS, bool EXACT, typename MidT>
 __global__ __launch_bounds__(256) void inv_t_kernel(const uint8_t* __restrict__ sym, MidT* __restrict__ mid, ChunkDims d,
                                                     Coeffs cf, int step0, int step1, int step2) {
-    const size_t plane = (size_t)d.pw * d.ph;
-    const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    __shared__ int lut[256];
+    const int tid = threadIdx.x;
     const int ch = blockIdx.y;
-    const int pf = d.pf, half = pf / 2, nf = d.f;
-    if (idx >= plane) return;
-    const int step = ch == 0 ? step0 : (ch == 1 ? step1 : step2);
-    const uint32_t* src = (const uint32_t*)(sym + (size_t)ch * pf * plane + idx);
-    MidT* dst = mid + (size_t)ch * pf * plane + idx;
-    const size_t plane4 = plane / 4;
-    // inverse step order (src/wavelet.rs:167-174): U2', P2', U1', P1' with negated coefficients
-    const int c0 = -cf.c[0], c1 = -cf.c[1], c2 = -cf.c[2], c3 = -cf.c[3];
-    I4 lo_c = dequant4(src[0], step), hi_c = dequant4(src[(size_t)half * plane4], step);  // E2[0], O2[0]
-    I4 o2p{}, e1p{}, o1pp{}, e0pp{};
-    const int last = (NS == 4) ? half + 1 : half;
-    for (int j = 0; j <= last; ++j) {
-        I4 lo_n{}, hi_n{};
-        if (j + 1 < half) {
-            lo_n = dequant4(src[(size_t)(j + 1) * plane4], step);
-            hi_n = dequant4(src[(size_t)(half + j + 1) * plane4], step);
-        }
-        if (NS == 4) {
-            I4 e1c{};
-            const bool havec = j < half;
-            if (havec) e1c = lift4<EXACT>(lo_c, (j >= 1) ? o2p : hi_c, hi_c, c3);        // U2': E1[j]
-            if (j >= 1) {
-                I4 o1p, e0p;
-                const bool have1 = j <= half;
-                if (have1) {
-                    o1p = lift4<EXACT>(o2p, e1p, havec ? e1c : e1p, c2);                 // P2': O1[j-1]
-                    e0p = lift4<EXACT>(e1p, (j >= 2) ? o1pp : o1p, o1p, c1);             // U1': E0[j-1]
-                    if (2 * (j - 1) < nf) store4<MidT>(dst + (size_t)(2 * (j - 1)) * plane, e0p);
-                }
-                if (j >= 2) {
-                    const I4 o0pp = lift4<EXACT>(o1pp, e0pp, have1 ? e0p : e0pp, c0);    // P1': O0[j-2]
-                    if (2 * (j - 2) + 1 < nf) store4<MidT>(dst + (size_t)(2 * (j - 2) + 1) * plane, o0pp);
-                }
-                if (have1) { o1pp = o1p; e0pp = e0p; }
-            }
-            if (havec) { o2p = hi_c; e1p = e1c; }
-        } else {
-            I4 e0c{};
-            const bool havec = j < half;
-            if (havec) {
-                e0c = lift4<EXACT>(lo_c, (j >= 1) ? o2p : hi_c, hi_c, c1);                // U1': E0[j]
-                if (2 * j < nf) store4<MidT>(dst + (size_t)(2 * j) * plane, e0c);
-            }
-            if (j >= 1) {
-                const I4 o0p = lift4<EXACT>(o2p, e1p, havec ? e0c : e1p, c0);            // P1': O0[j-1]
-                if (2 * (j - 1) + 1 < nf) store4<MidT>(dst + (size_t)(2 * (j - 1) + 1) * plane, o0p);
-            }
-            if (havec) { o2p = hi_c; e1p = e0c; }
-        }
-        lo_c = lo_n; hi_c = hi_n;
+    {
+        const int step = ch == 0 ? step0 : (ch == 1 ? step1 : step2);
+        const int s = tid;
+        const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));  // src/quant.rs:581-587
+        lut[s] = (int)((unsigned)q * (unsigned)step);                      // src/quant.rs:104-110 (wrapping)
     }
+    __syncthreads();
+    const size_t plane = (size_t)d.pw * d.ph;
+    const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
+    if (idx >= plane) return;
+    const int half = (int)d.pf / 2;
+    InvT<NS, EXACT, MidT> f;
+    f.src = (const char*)(sym + (size_t)ch * d.pf * plane);
+    f.dst = mid + (size_t)ch * d.pf * plane + idx;
+    f.plane = plane; f.off8 = (uint32_t)idx; f.half = half; f.nf = (int)d.f;
+    f.c0 = -cf.c[0]; f.c1 = -cf.c[1]; f.c2 = -cf.c[2]; f.c3 = -cf.c[3];
+    f.lut = lut;
+    f.o2p = I4{}; f.e1p = I4{}; f.o1pp = I4{}; f.e0pp = I4{};
+    uint32_t rl[4] = {0u, 0u, 0u, 0u}, rh[4] = {0u, 0u, 0u, 0u};   // symbols in flight; slot = pair & 3 (static)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < half) f.load_pair(i, rl[i], rh[i]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u < half) {
+            if (u + 3 < half) f.load_pair(u + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
+            if (u == 0) f.template tick<true, false>(u, rl[u], rh[u]);
+            else if (u == 1) f.template tick<false, true>(u, rl[u], rh[u]);
+            else f.template tick<false, false>(u, rl[u], rh[u]);
+        }
+    }
+    int kb = 4;
+    for (; kb + 4 <= half; kb += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kb + u;
+            if (k + 3 < half) f.load_pair(k + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
+            f.template tick<false, false>(k, rl[u], rh[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = kb + u;
+        if (k < half) {
+            if (k + 3 < half) f.load_pair(k + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
+            f.template tick<false, false>(k, rl[u], rh[u]);
+        }
+    }
+    f.flush();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,26 +600,24 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
     const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
     const int gpx0 = (gx0 - H) / 2;  // first column pair of the extended tile (may be negative)
 
-    // stage A: one thread per (extended column, channel): inverse column lifting in registers
+    // stage A: one thread per (extended column, channel): inverse column lifting in registers.  Rows and
+    // columns outside the frame are read through the symmetric extension (reflect_idx), in the interleaved
+    // index space, so neither stage needs boundary logic in its arithmetic.
     if (tid < 3 * EC) {
         const int ch = tid / EC, xq = tid % EC;
         const int par = xq / ECh, j = xq % ECh;
-        const int gxp = gpx0 + j;
-        if (!EDGE || (gxp >= 0 && gxp < hw)) {
+        const int px = EDGE ? reflect_idx(2 * (gpx0 + j) + par, pw) : 2 * (gpx0 + j) + par;   // parity is preserved
+        {
             int v[ER];
-            const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
+            const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + (px >> 1);
             const int gy_s = gy0 - H;
 #pragma unroll
             for (int k = 0; k < ER; ++k) {
-                const int gy = gy_s + k;
-                int val = 0;
-                if (!EDGE || (gy >= 0 && gy < ph)) {
-                    const int yy = (gy & 1) * hh + (gy >> 1);
-                    val = (int)src[(size_t)yy * pw];
-                }
-                v[k] = val;
+                const int gy = EDGE ? reflect_idx(gy_s + k, ph) : gy_s + k;
+                const int yy = (gy & 1) * hh + (gy >> 1);
+                v[k] = (int)src[(size_t)yy * pw];
             }
-            lift_regs<ER, NS, EDGE, EXACT, true>(v, cf, gy_s, ph);
+            lift_regs<ER, NS, false, EXACT, true>(v, cf, 0, 0);
             int* L = lds + (ch * ER) * LW + xq;
 #pragma unroll
             for (int k = 0; k < ER; ++k) L[k * LW] = v[k];
@@ -504,10 +642,9 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
                 const int q = (lx & 1) * ECh + (lx >> 1);
                 y[k] = L0[q]; co[k] = L1[q]; cg[k] = L2[q];
             }
-            const int g0 = gxs - H;
-            lift_regs<NL, NS, EDGE, EXACT, true>(y, cf, g0, pw);
-            lift_regs<NL, NS, EDGE, EXACT, true>(co, cf, g0, pw);
-            lift_regs<NL, NS, EDGE, EXACT, true>(cg, cf, g0, pw);
+            lift_regs<NL, NS, false, EXACT, true>(y, cf, 0, 0);
+            lift_regs<NL, NS, false, EXACT, true>(co, cf, 0, 0);
+            lift_regs<NL, NS, false, EXACT, true>(cg, cf, 0, 0);
             uint8_t out[I_SEG * 3];
 #pragma unroll
             for (int k = 0; k < I_SEG; ++k) {
@@ -557,6 +694,8 @@ static bool set_dyn_lds(K kernel, size_t bytes) {
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
                               int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
     if (step < 1 || step > 64) return false;
+    if ((unsigned long long)d.pw * d.ph > (1ull << 30)) return false;   // 32-bit byte offsets inside one frame
+    if (d.pw < 6 || d.ph < 6) return false;                             // reflect_idx: one reflection must cover the halo
     if ((unsigned long long)((d.pw + F_TW - 1) / F_TW) * ((d.ph + F_TH - 1) / F_TH) * d.pf > 0x7FFFFFF0ull) return false;
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
@@ -624,6 +763,8 @@ bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wave
                               bool exact, bool mid16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
+    if ((unsigned long long)d.pw * d.ph > (1ull << 30)) return false;   // 32-bit byte offsets inside one frame
+    if (d.pw < 6 || d.ph < 6) return false;                             // reflect_idx: one reflection must cover the halo
     if ((unsigned long long)((d.w + I_TW - 1) / I_TW) * ((d.h + I_TH - 1) / I_TH) * d.f > 0x7FFFFFF0ull) return false;
     // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too)
     if (ls.n == 4) {
