@@ -304,7 +304,7 @@ struct EncodeWork {
     ChunkDims d{};
     int n_chunks = 0;
     uint64_t cap = 0, alc_stride = 0;
-    DevBuf mid, tmp, sym, hist, tables, streams, results, alc, sizes, planes;
+    DevBuf mid, tmp, sym, hist, tables, results, alc, sizes, planes;
 };
 
 int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks) {
@@ -318,15 +318,15 @@ int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks) {
     return kOk;
 }
 
-// Stream regions and .alc buffers for a per-chain capacity (re-allocated only when it grows).
+// .alc buffers for a per-chain capacity (re-allocated only when it grows).  A chunk's buffer is
+// [kStreamHead bytes][3 regions of cap bytes]: the chains write their streams at the tails of the regions and the
+// compaction moves them, in place, behind the header at the front.
 int encode_work_set_cap(EncodeWork& w, uint64_t cap) {
-    if (cap <= w.cap && w.streams.p && w.alc.p) return kOk;
-    w.streams.reset();
+    if (cap <= w.cap && w.alc.p) return kOk;
     w.alc.reset();
     w.cap = cap;
-    w.alc_stride = round_up((uint64_t)kAlcHeaderBytes + 3 * cap, 256);
-    TRY(w.streams.alloc((size_t)w.n_chunks * 3 * cap + 256));  // slack: the compaction copy reads whole dwords
-    TRY(w.alc.alloc((size_t)w.n_chunks * w.alc_stride));
+    w.alc_stride = round_up(kStreamHead + 3 * cap, 256);
+    TRY(w.alc.alloc((size_t)w.n_chunks * w.alc_stride + 256));  // slack: the compaction copy reads whole dwords
     return kOk;
 }
 
@@ -424,13 +424,12 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[2], st));
-    launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.streams.as<uint8_t>(),
-                       w.cap, w.results.as<RansResult>(), 3 * B, st);
+    launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.alc.as<uint8_t>(),
+                       w.cap, w.results.as<RansResult>(), 3 * B, st, w.alc_stride, kStreamHead);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[3], st));
     launch_write_headers(w.alc.as<uint8_t>(), w.alc_stride, d, wavelet, step, w.hist.as<uint32_t>(),
                          w.results.as<RansResult>(), w.sizes.as<unsigned long long>(), B, st);
-    launch_compact_streams(w.alc.as<uint8_t>(), w.alc_stride, w.streams.as<uint8_t>(), w.cap,
-                           w.results.as<RansResult>(), B, st);
+    launch_compact_streams(w.alc.as<uint8_t>(), w.alc_stride, kStreamHead, w.cap, w.results.as<RansResult>(), B, st);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[4], st));
     HIP_TRY(hipGetLastError());
     return kOk;

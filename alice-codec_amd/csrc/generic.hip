@@ -376,41 +376,67 @@ __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict_
         put_u32le(p + kFixedHeaderBytes + c * kChannelHeaderBytes + 16 + 4 * tid, hist[((size_t)chunk * 3 + c) * 256 + tid]);
 }
 
-// Moves the three streams of each chunk (each sits at the tail of its cap-sized region)
-// to directly behind the header.  grid = (blocks_per_chunk, n_chunks).
-__global__ __launch_bounds__(256) void compact_streams_kernel(uint8_t* __restrict__ alc, unsigned long long alc_stride,
-                                                              const uint8_t* __restrict__ streams, unsigned long long cap,
-                                                              const RansResult* __restrict__ res) {
-    const int chunk = blockIdx.y;
-    uint8_t* dst = alc + (size_t)chunk * alc_stride + kAlcHeaderBytes;
-    const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, nthreads = (unsigned long long)gridDim.x * 256;
+// Moves the three streams of a chunk (each sits at the tail of its cap-sized region inside the chunk's own
+// .alc buffer) to directly behind the header, IN PLACE.  Every byte moves towards lower addresses, so a
+// front-to-back copy is safe as long as a block of the source has been read completely before anything at
+// or beyond its destination is written: one workgroup per chunk walks the stream in 64 KB blocks,
+// load (all threads) -> barrier -> store.  The destination of block k ends where the source of block k
+// began or earlier, so it can only overlap sources that have already been read.
+constexpr int kCompactThreads = 1024, kCompactVecs = 4;
+__global__ __launch_bounds__(kCompactThreads) void compact_streams_kernel(uint8_t* __restrict__ alc, unsigned long long alc_stride,
+                                                                         unsigned long long head_bytes, unsigned long long cap,
+                                                                         const RansResult* __restrict__ res) {
+    const int chunk = blockIdx.x;
+    const unsigned tid = threadIdx.x;
+    uint8_t* const base = alc + (size_t)chunk * alc_stride;
+    uint8_t* dst = base + kAlcHeaderBytes;
     for (int c = 0; c < 3; ++c) {
         // never touch memory for a chain that overflowed its region (its length exceeds the capacity)
         const RansResult rr = res[chunk * 3 + c];
         const unsigned long long len = ((rr.flags & kRansOverflow) || rr.len > cap) ? 0ull : rr.len;
-        const uint8_t* src = streams + ((size_t)chunk * 3 + c) * cap + (cap - len);
+        const uint8_t* src = base + head_bytes + (size_t)(c + 1) * cap - len;
         // bytes up to the first 16-byte boundary of dst, then 16 B stores fed by (possibly unaligned) 4 B loads
         unsigned long long head = (16u - (unsigned)((uintptr_t)dst & 15u)) & 15u;
         if (head > len) head = len;
-        for (unsigned long long i = tid; i < head; i += nthreads) dst[i] = src[i];
         const unsigned long long nvec = (len - head) / 16;
+        const unsigned long long tail0 = head + nvec * 16;
+        // head and tail bytes: read now, written after the first barrier (a later block may overwrite their source)
+        uint8_t hb = 0, tb = 0;
+        if (tid < head) hb = src[tid];
+        if (tail0 + tid < len) tb = src[tail0 + tid];
         const unsigned mis = (unsigned)((uintptr_t)(src + head) & 3u);
-        for (unsigned long long v = tid; v < nvec; v += nthreads) {
-            const uint8_t* sp = src + head + v * 16;
-            uint32_t w[4];
-            if (mis == 0) {
-                const uint32_t* s4 = (const uint32_t*)sp;
-                w[0] = s4[0]; w[1] = s4[1]; w[2] = s4[2]; w[3] = s4[3];
-            } else {
-                const uint32_t* s4 = (const uint32_t*)(sp - mis);
-                uint32_t t0 = s4[0], t1 = s4[1], t2 = s4[2], t3 = s4[3], t4 = s4[4];
-                const unsigned sh = mis * 8;
-                w[0] = (t0 >> sh) | (t1 << (32 - sh)); w[1] = (t1 >> sh) | (t2 << (32 - sh));
-                w[2] = (t2 >> sh) | (t3 << (32 - sh)); w[3] = (t3 >> sh) | (t4 << (32 - sh));
+        const unsigned sh = mis * 8;
+        const unsigned long long per_block = (unsigned long long)kCompactThreads * kCompactVecs;
+        bool first = true;
+        for (unsigned long long v0 = 0; v0 < nvec || first; v0 += per_block) {
+            uint4 w[kCompactVecs];
+#pragma unroll
+            for (int u = 0; u < kCompactVecs; ++u) {
+                const unsigned long long v = v0 + (unsigned long long)u * kCompactThreads + tid;
+                if (v < nvec) {
+                    const uint32_t* s4 = (const uint32_t*)(src + head + v * 16 - mis);
+                    if (mis == 0) {
+                        w[u] = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+                    } else {
+                        const uint32_t t0 = s4[0], t1 = s4[1], t2 = s4[2], t3 = s4[3], t4 = s4[4];
+                        w[u] = make_uint4((t0 >> sh) | (t1 << (32 - sh)), (t1 >> sh) | (t2 << (32 - sh)),
+                                          (t2 >> sh) | (t3 << (32 - sh)), (t3 >> sh) | (t4 << (32 - sh)));
+                    }
+                }
             }
-            *(uint4*)(dst + head + v * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            __syncthreads();
+            if (first) {
+                if (tid < head) dst[tid] = hb;
+                first = false;
+            }
+#pragma unroll
+            for (int u = 0; u < kCompactVecs; ++u) {
+                const unsigned long long v = v0 + (unsigned long long)u * kCompactThreads + tid;
+                if (v < nvec) *(uint4*)(dst + head + v * 16) = w[u];
+            }
         }
-        for (unsigned long long i = head + nvec * 16 + tid; i < len; i += nthreads) dst[i] = src[i];
+        if (tail0 + tid < len) dst[tail0 + tid] = tb;
+        __syncthreads();   // the next stream's destination may cover this stream's source
         dst += len;
     }
 }
@@ -422,11 +448,11 @@ void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& 
     hipLaunchKernelGGL(write_headers_kernel, dim3(n_chunks), dim3(256), 0, st, d_alc, (unsigned long long)alc_stride, d,
                        wavelet, step, d_hist, d_results, d_sizes);
 }
-void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, const uint8_t* d_streams, uint64_t cap,
+void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, uint64_t head, uint64_t cap,
                             const RansResult* d_results, int n_chunks, hipStream_t st) {
     if (n_chunks <= 0) return;
-    hipLaunchKernelGGL(compact_streams_kernel, dim3(1024, n_chunks), dim3(256), 0, st, d_alc,
-                       (unsigned long long)alc_stride, d_streams, (unsigned long long)cap, d_results);
+    hipLaunchKernelGGL(compact_streams_kernel, dim3(n_chunks), dim3(kCompactThreads), 0, st, d_alc,
+                       (unsigned long long)alc_stride, (unsigned long long)head, (unsigned long long)cap, d_results);
 }
 
 }  // namespace alice

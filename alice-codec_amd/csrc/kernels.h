@@ -28,10 +28,13 @@ struct RansDecodeDesc {
 void launch_rans_table(const uint32_t* d_hist, RansTable* d_tables, int n_chains, hipStream_t st);
 void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq, RansTable* d_table,
                                    hipStream_t st);
-// chain c reads sym + c*sym_stride (n symbols) and writes its stream back-to-front into
-// [out + c*cap, out + (c+1)*cap); the stream is the last results[c].len bytes of that region.
+// chain c reads sym + c*sym_stride (n symbols) and writes its stream back-to-front into a cap-sized region;
+// the stream is the last results[c].len bytes of that region.  group_stride == 0: region c starts at
+// out + c*cap.  Otherwise chains 3g, 3g+1, 3g+2 write into chunk g's .alc buffer: region start =
+// out + g*group_stride + group_head + (c % 3)*cap.
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
-                        uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st);
+                        uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
+                        uint64_t group_stride = 0, uint64_t group_head = 0);
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
 
 // ---- transform.hip (pipeline-specialised: RGB <-> u8 symbols) ----
@@ -62,9 +65,10 @@ void launch_to_symbols(const int32_t* in, uint8_t* out, uint64_t n, hipStream_t 
 void launch_from_symbols(const uint8_t* in, int32_t* out, uint64_t n, hipStream_t st);
 void launch_histogram(const uint8_t* sym, uint64_t n, uint32_t* hist /*zeroed*/, hipStream_t st);
 void launch_sq_diff_sum(const uint8_t* a, const uint8_t* b, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st);
-// copies the three streams (each at the tail of its cap-sized region) behind a 3138-byte
-// header slot: d_alc[chunk*alc_stride + 3138 ...]; writes per-chunk total sizes.
-void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, const uint8_t* d_streams, uint64_t cap,
+// Each chunk's .alc buffer holds, behind `head` bytes, three cap-sized regions with a stream at the tail of
+// each; moves the streams, in place, to directly behind the 3138-byte header slot.
+constexpr uint64_t kStreamHead = 3328;   // >= kAlcHeaderBytes, multiple of 256
+void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, uint64_t head, uint64_t cap,
                             const RansResult* d_results, int n_chunks, hipStream_t st);
 // fills the 3138-byte headers on the device (magic, dims, per-channel fields, histograms)
 void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& d, int wavelet, int32_t step,

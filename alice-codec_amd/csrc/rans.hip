@@ -189,6 +189,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                                                          const RansTable* __restrict__ tables,
                                                          uint8_t* __restrict__ out_base,
                                                          unsigned long long cap,
+                                                         unsigned long long group_stride,
+                                                         unsigned long long group_head,
                                                          RansResult* __restrict__ results) {
     __shared__ uint4 tab_a[256];  // xmax, xmax8, rcp, rsh
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     const int lane = threadIdx.x;
     const uint8_t* __restrict__ sym = sym_base + (size_t)chain * sym_stride;
     const RansTable* __restrict__ tbl = tables + chain;
-    uint8_t* const region = out_base + (size_t)chain * cap;
+    // group_stride == 0: regions back to back.  Otherwise the three chains of chunk g write into the chunk's own
+    // .alc buffer, behind `group_head` bytes kept free for the header (the streams are compacted in place later).
+    uint8_t* const region = group_stride == 0ull ? out_base + (size_t)chain * cap
+                                                 : out_base + (size_t)(chain / 3) * group_stride + group_head + (size_t)(chain % 3) * cap;
     uint8_t* const out_end = region + cap;
     // lanes that have nothing to emit store to a private byte at the unused front of the region instead
     // of branching around the store; the capacity test keeps real bytes 64 bytes away from it
@@ -576,11 +581,12 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
 }
 
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
-                        uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st) {
+                        uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
+                        uint64_t group_stride, uint64_t group_head) {
     if (n_chains <= 0) return;
     hipLaunchKernelGGL(rans_encode_kernel, dim3(n_chains), dim3(64), 0, st, d_sym,
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
-                       (unsigned long long)cap, d_results);
+                       (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, d_results);
 }
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {

@@ -87,6 +87,20 @@ def test_more_than_64_frames_uses_generic_kernels(gpu_codec, oracle_mod):
         assert np.array_equal(gpu_codec.FrameDecoder().decode(chunk), oracle_mod.decode(ref))
 
 
+@pytest.mark.parametrize("k", [0, 1])
+def test_every_frame_count_through_the_streaming_temporal_pass(gpu_codec, oracle_mod, k):
+    """The temporal kernels run pairs in blocks of four with peeled first/last blocks: cover every residue and
+    every short length (f = 1 pads to 2; odd f pads by one frame)."""
+    w, h, q = 12, 10, 85
+    enc = gpu_codec.FrameEncoder.with_wavelet(q, gpu_codec.WaveletType(k))
+    for f in list(range(1, 28)) + [31, 32, 33, 34, 35, 40, 41]:
+        rgb = np.random.default_rng(1000 + f).integers(0, 256, w * h * f * 3, dtype=np.uint8)
+        ref = oracle_mod.encode(rgb, w, h, f, q, k)
+        chunk = enc.encode(rgb, w, h, f)
+        assert chunk.to_bytes() == ref, (f, first_diff(chunk.to_bytes(), ref))
+        assert np.array_equal(gpu_codec.FrameDecoder().decode(chunk), oracle_mod.decode(ref)), f
+
+
 def test_empty_chunk(gpu_codec):  # src/pipeline.rs:738-743, 764-769
     c = gpu_codec.FrameEncoder(50).encode(np.zeros(0, np.uint8), 0, 0, 0)
     assert c.compressed_size() == 0 and gpu_codec.FrameDecoder().decode(c).size == 0
