@@ -162,6 +162,8 @@ def load_library() -> C.CDLL:
         "alice_codec_freq_table_from_histogram": (C.c_int, [_u32p, _u16p, _u16p]),
         "alice_codec_rans_encode": (vp, [_u8p, C.c_uint64, _u16p, _u16p, _u64p]),
         "alice_codec_rans_decode": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
+        "alice_codec_rans_encode_interleaved": (vp, [_u8p, C.c_uint64, _u16p, _u16p, _u64p]),
+        "alice_codec_rans_decode_interleaved": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
         "alice_codec_rgb_to_ycocg_r": (C.c_int, [_u8p, C.c_uint64, _i16p, _i16p, _i16p, C.c_uint64]),
         "alice_codec_ycocg_r_to_rgb": (C.c_int, [_i16p, _i16p, _i16p, C.c_uint64, _u8p, C.c_uint64]),
         "alice_codec_dev_forward_symbols": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, vp, vp, vp]),
@@ -615,6 +617,46 @@ class RansDecoder:
                                                       _p(table.cum_freq, _u16p), _p(table.freq, _u16p), n,
                                                       _p(out, _u8p) if n else z))
         return out
+
+
+class InterleavedRansEncoder:
+    """reference src/rans.rs:393-456: four interleaved streams (an opt-in format; `.alc` v1 uses RansEncoder)."""
+
+    def __init__(self): self._pending = None
+
+    def encode(self, symbols, table: FrequencyTable) -> None:
+        self._pending = (_as_u8(symbols).copy(), table)
+
+    def finish(self) -> bytes:
+        lib = load_library()
+        sym, table = self._pending if self._pending is not None else (np.zeros(0, np.uint8), FrequencyTable.uniform())
+        n = C.c_uint64()
+        z = C.cast(C.c_char_p(b""), _u8p)
+        p = lib.alice_codec_rans_encode_interleaved(_p(sym, _u8p) if sym.size else z, sym.size, _p(table.cum_freq, _u16p),
+                                                    _p(table.freq, _u16p), C.byref(n))
+        if not p:
+            _raise_last()
+        try:
+            return _copy_out(p, n.value).tobytes()
+        finally:
+            lib.alice_codec_data_free64(p, n.value)
+
+
+class InterleavedRansDecoder:
+    """reference src/rans.rs:468-519 (SimdRansDecoder, :531-666, decodes the same format to the same symbols)."""
+
+    def __init__(self, data): self._data = _as_u8(data).copy()
+
+    def decode_n(self, n: int, table: FrequencyTable) -> np.ndarray:
+        out = np.zeros(n, np.uint8)
+        z = C.cast(C.c_char_p(b""), _u8p)
+        _check(load_library().alice_codec_rans_decode_interleaved(_p(self._data, _u8p) if self._data.size else z, self._data.size,
+                                                                  _p(table.cum_freq, _u16p), _p(table.freq, _u16p), n,
+                                                                  _p(out, _u8p) if n else z))
+        return out
+
+
+SimdRansDecoder = InterleavedRansDecoder
 
 
 # ---------------------------------------------------------------------------------------------

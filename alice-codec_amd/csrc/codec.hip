@@ -1136,6 +1136,113 @@ int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t c
     return kOk;
 }
 
+// InterleavedRansEncoder::{encode, finish} (src/rans.rs:393-456): four independent single-stream coders over the
+// sub-sequences i = j mod 4, behind a 32-byte header (4 stream lengths, 4 symbol counts, u32 LE).  On the GPU
+// that is four chains of the same encode kernel running side by side.
+uint8_t* alice_codec_rans_encode_interleaved(const uint8_t* symbols, uint64_t n, const uint16_t cum_freq[256],
+                                             const uint16_t freq[256], uint64_t* out_len) {
+    clear_error();
+    if ((!symbols && n) || !cum_freq || !freq || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
+    hipStream_t st;
+    if (get_stream(&st)) return nullptr;
+    uint64_t cnt[4];
+    unsigned split = 0;
+    for (int j = 0; j < 4; ++j) cnt[j] = (n + 3 - j) / 4;        // :423-425
+    for (int j = 0; j < 4; ++j) split += cnt[j] == cnt[0];
+    if (cnt[0] > 0xFFFFFFFFull) { fail(kDimensionOverflow, "symbol count does not fit the u32 header field"); return nullptr; }
+    const uint64_t stride = round_up(cnt[0] + 16, 256);
+    const uint64_t cap = round_up(2 * cnt[0] + 4 + 64 + 64, 256);
+    DevBuf ds, d4, dc, df, dt, dout, dres;
+    if (ds.alloc(n) || d4.alloc(4 * stride) || dc.alloc(512) || df.alloc(512) || dt.alloc(4 * sizeof(RansTable)) ||
+        dout.alloc(4 * cap) || dres.alloc(4 * sizeof(RansResult))) return nullptr;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess) { fail(kDeviceError, hipGetErrorString(e)); return false; } return true; };
+    if (n && !ok(hipMemcpyAsync(ds.p, symbols, n, hipMemcpyHostToDevice, st))) return nullptr;
+    if (!ok(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st)) || !ok(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st))) return nullptr;
+    launch_split4(ds.as<uint8_t>(), n, d4.as<uint8_t>(), stride, st);
+    for (int j = 0; j < 4; ++j) launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>() + j, st);
+    launch_rans_encode(d4.as<uint8_t>(), stride, cnt[0], dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), 4, st,
+                       0, 0, split);
+    RansResult res[4];
+    if (!ok(hipMemcpyAsync(res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) return nullptr;
+    uint64_t total = 32;
+    for (int j = 0; j < 4; ++j) {
+        if (res[j].flags & kTableDiverges) { fail(kReferenceDiverges, "symbol with table frequency 0 encoded"); return nullptr; }
+        if (res[j].flags & (kRansOverflow | kRansInternal)) { fail(kInternal, "rANS encode failed"); return nullptr; }
+        if (res[j].len > 0xFFFFFFFFull) { fail(kDimensionOverflow, "stream length does not fit the u32 header field"); return nullptr; }
+        total += res[j].len;
+    }
+    uint8_t* p = (uint8_t*)malloc(total);
+    if (!p) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    uint64_t off = 32;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t l = (uint32_t)res[j].len, c = (uint32_t)cnt[j];
+        memcpy(p + 4 * j, &l, 4);
+        memcpy(p + 16 + 4 * j, &c, 4);
+        if (!ok(hipMemcpyAsync(p + off, dout.as<uint8_t>() + (size_t)j * cap + (cap - res[j].len), res[j].len, hipMemcpyDeviceToHost, st))) { free(p); return nullptr; }
+        off += res[j].len;
+    }
+    if (!ok(hipStreamSynchronize(st))) { free(p); return nullptr; }
+    *out_len = total;
+    return p;
+}
+
+// InterleavedRansDecoder::{new, decode_n} (src/rans.rs:468-519; SimdRansDecoder reads the same format): the four
+// streams are decoded by four chains, then merged in the reference's round-robin order (streams that run out
+// are skipped).  Where the reference would index out of bounds or spin forever this returns an error.
+int alice_codec_rans_decode_interleaved(const uint8_t* bytes, uint64_t len, const uint16_t cum_freq[256],
+                                        const uint16_t freq[256], uint64_t n, uint8_t* symbols) {
+    clear_error();
+    if ((!bytes && len) || !cum_freq || !freq || (!symbols && n)) return fail(kNullArgument, "null argument");
+    if (len < 32) return fail(kInvalidBitstream, "interleaved stream shorter than its 32-byte header");
+    uint64_t slen[4], cnt[4], total = 0, end = 32;
+    for (int j = 0; j < 4; ++j) {
+        uint32_t a, b;
+        memcpy(&a, bytes + 4 * j, 4); memcpy(&b, bytes + 16 + 4 * j, 4);
+        slen[j] = a; cnt[j] = b; total += b; end += a;
+    }
+    if (end > len) return fail(kInvalidBitstream, "stream lengths exceed the input");
+    if (n > total) return fail(kReferenceDiverges, "more symbols requested than the header counts hold: the reference decoder does not terminate");
+    if (!n) return kOk;
+    // symbols of stream j that land below position n: pos(j, k) = sum_i min(cnt_i, k) + #{i < j : cnt_i > k}
+    auto pos = [&](int j, uint64_t k) {
+        uint64_t p = 0;
+        for (int i = 0; i < 4; ++i) { p += std::min(cnt[i], k); if (i < j && cnt[i] > k) ++p; }
+        return p;
+    };
+    uint64_t need[4], mx = 0;
+    for (int j = 0; j < 4; ++j) {
+        uint64_t lo = 0, hi = cnt[j];      // first k with pos(j, k) >= n
+        while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (pos(j, mid) >= n) hi = mid; else lo = mid + 1; }
+        need[j] = lo; mx = std::max(mx, lo);
+    }
+    hipStream_t st;
+    TRY(get_stream(&st));
+    const uint64_t stride = round_up(mx + 16, 256);
+    DevBuf din, dc, df, dt, d4, dout, ddesc, dres;
+    TRY(din.alloc(len + 16)); TRY(dc.alloc(512)); TRY(df.alloc(512)); TRY(dt.alloc(sizeof(RansTable)));
+    TRY(d4.alloc(4 * stride)); TRY(dout.alloc(n)); TRY(ddesc.alloc(4 * sizeof(RansDecodeDesc))); TRY(dres.alloc(4 * sizeof(RansResult)));
+    HIP_TRY(hipMemcpyAsync(din.p, bytes, len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
+    RansDecodeDesc desc[4];
+    uint64_t off = 32;
+    for (int j = 0; j < 4; ++j) {
+        desc[j] = RansDecodeDesc{din.as<uint8_t>() + off, slen[j], d4.as<uint8_t>() + (size_t)j * stride, need[j], dt.as<RansTable>()};
+        off += slen[j];
+    }
+    HIP_TRY(hipMemcpyAsync(ddesc.p, desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
+    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 4, st);
+    launch_merge4(d4.as<uint8_t>(), stride, need, cnt, dout.as<uint8_t>(), n, st);
+    RansResult res[4];
+    HIP_TRY(hipMemcpyAsync(res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(symbols, dout.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (auto& r : res)
+        if (r.flags & kRansInternal) return fail(kInternal, "decode table outside the packed range (freq > 4096 with live slots)");
+    return kOk;
+}
+
 int alice_codec_rgb_to_ycocg_r(const uint8_t* rgb, uint64_t rgb_len, int16_t* y, int16_t* co, int16_t* cg, uint64_t n_out) {
     clear_error();
     if (rgb_len % 3 != 0) return fail(kInvalidBufferSize, "rgb length is not a multiple of 3");  // src/color.rs:205-210

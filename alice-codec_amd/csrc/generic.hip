@@ -441,6 +441,40 @@ __global__ __launch_bounds__(kCompactThreads) void compact_streams_kernel(uint8_
     }
 }
 
+__global__ __launch_bounds__(256) void split4_kernel(const uint8_t* __restrict__ in, unsigned long long n,
+                                                     uint8_t* __restrict__ out, unsigned long long stride) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[(i & 3ull) * stride + (i >> 2)] = in[i];
+}
+struct Count4 { unsigned long long c[4]; };
+__global__ __launch_bounds__(256) void merge4_kernel(const uint8_t* __restrict__ in, unsigned long long stride, Count4 have,
+                                                     Count4 cnt, uint8_t* __restrict__ out, unsigned long long n_out) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (k >= have.c[j]) return;
+    unsigned long long pos = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pos += cnt.c[i] < k ? cnt.c[i] : k;
+        if (i < j && cnt.c[i] > k) ++pos;
+    }
+    if (pos < n_out) out[pos] = in[(size_t)j * stride + k];
+}
+void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t stride, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(split4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, (unsigned long long)n, d_out,
+                       (unsigned long long)stride);
+}
+void launch_merge4(const uint8_t* d_in, uint64_t stride, const uint64_t have[4], const uint64_t count[4], uint8_t* d_out,
+                   uint64_t n_out, hipStream_t st) {
+    Count4 h{{have[0], have[1], have[2], have[3]}}, c{{count[0], count[1], count[2], count[3]}};
+    uint64_t mx = 0;
+    for (int i = 0; i < 4; ++i) mx = have[i] > mx ? have[i] : mx;
+    if (!mx || !n_out) return;
+    hipLaunchKernelGGL(merge4_kernel, dim3((unsigned)((mx + 255) / 256), 4), dim3(256), 0, st, d_in, (unsigned long long)stride, h, c,
+                       d_out, (unsigned long long)n_out);
+}
+
 void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& d, int wavelet, int32_t step,
                           const uint32_t* d_hist, const RansResult* d_results, unsigned long long* d_sizes,
                           int n_chunks, hipStream_t st) {

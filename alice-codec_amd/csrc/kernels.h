@@ -31,10 +31,17 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
 // chain c reads sym + c*sym_stride (n symbols) and writes its stream back-to-front into a cap-sized region;
 // the stream is the last results[c].len bytes of that region.  group_stride == 0: region c starts at
 // out + c*cap.  Otherwise chains 3g, 3g+1, 3g+2 write into chunk g's .alc buffer: region start =
-// out + g*group_stride + group_head + (c % 3)*cap.
+// out + g*group_stride + group_head + (c % 3)*cap.  Chains c >= n_split encode n - 1 symbols.
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
-                        uint64_t group_stride = 0, uint64_t group_head = 0);
+                        uint64_t group_stride = 0, uint64_t group_head = 0, unsigned n_split = 0xFFFFFFFFu);
+// out_j[k] = in[4k + j] for the four sub-sequences of an interleaved stream (out_j = out + j*stride)
+void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t stride, hipStream_t st);
+// InterleavedRansDecoder::decode_n order (src/rans.rs:501-519): symbol k of stream j lands at
+// sum_i min(count_i, k) + #{i < j : count_i > k}; positions >= n_out are dropped.  have[j] symbols of stream j
+// are present in d_in (the ones that land below n_out), count[j] is the header's count.
+void launch_merge4(const uint8_t* d_in, uint64_t stride, const uint64_t have[4], const uint64_t count[4], uint8_t* d_out,
+                   uint64_t n_out, hipStream_t st);
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
 
 // ---- transform.hip (pipeline-specialised: RGB <-> u8 symbols) ----

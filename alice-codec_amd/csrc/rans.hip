@@ -185,12 +185,13 @@ __device__ __forceinline__ void ripple64(uint32_t& xin, uint32_t& xout, uint32_t
 
 __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restrict__ sym_base,
                                                          unsigned long long sym_stride,
-                                                         unsigned long long n,
+                                                         unsigned long long n_first,
                                                          const RansTable* __restrict__ tables,
                                                          uint8_t* __restrict__ out_base,
                                                          unsigned long long cap,
                                                          unsigned long long group_stride,
                                                          unsigned long long group_head,
+                                                         unsigned n_split,
                                                          RansResult* __restrict__ results) {
     __shared__ uint4 tab_a[256];  // xmax, xmax8, rcp, rsh
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
@@ -198,6 +199,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
 
     const int chain = blockIdx.x;
     const int lane = threadIdx.x;
+    // chains from n_split on carry one symbol less (the sub-sequences of an interleaved stream)
+    const unsigned long long n = n_first - (((unsigned)chain >= n_split && n_first > 0ull) ? 1ull : 0ull);
     const uint8_t* __restrict__ sym = sym_base + (size_t)chain * sym_stride;
     const RansTable* __restrict__ tbl = tables + chain;
     // group_stride == 0: regions back to back.  Otherwise the three chains of chunk g write into the chunk's own
@@ -582,11 +585,12 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
 
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
-                        uint64_t group_stride, uint64_t group_head) {
+                        uint64_t group_stride, uint64_t group_head, unsigned n_split) {
     if (n_chains <= 0) return;
     hipLaunchKernelGGL(rans_encode_kernel, dim3(n_chains), dim3(64), 0, st, d_sym,
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
-                       (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, d_results);
+                       (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, n_split,
+                       d_results);
 }
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {

@@ -171,6 +171,15 @@ uint8_t *alice_codec_rans_encode(const uint8_t *symbols, uint64_t n, const uint1
 /* RansDecoder::new(bytes).decode_n(n, table) (src/rans.rs:330-381); cum_to_sym is rebuilt from the arrays */
 int alice_codec_rans_decode(const uint8_t *bytes, uint64_t len, const uint16_t cum_freq[256],
                             const uint16_t freq[256], uint64_t n, uint8_t *symbols);
+/* InterleavedRansEncoder::new().encode(symbols, table).finish() (src/rans.rs:393-456): 32-byte header + four
+ * independent streams over the sub-sequences i = j mod 4 (an opt-in format, not used by .alc v1).
+ * Returns a buffer to free with alice_codec_data_free64, NULL on error. */
+uint8_t *alice_codec_rans_encode_interleaved(const uint8_t *symbols, uint64_t n, const uint16_t cum_freq[256],
+                                             const uint16_t freq[256], uint64_t *out_len);
+/* InterleavedRansDecoder::new(bytes).decode_n(n, table) (src/rans.rs:468-519; SimdRansDecoder, :531-666, reads
+ * the same format).  Inputs on which the reference indexes out of bounds or never terminates give an error. */
+int alice_codec_rans_decode_interleaved(const uint8_t *bytes, uint64_t len, const uint16_t cum_freq[256],
+                                        const uint16_t freq[256], uint64_t n, uint8_t *symbols);
 /* rgb_bytes_to_ycocg_r / ycocg_r_to_rgb_bytes (src/color.rs:199-276) */
 int alice_codec_rgb_to_ycocg_r(const uint8_t *rgb, uint64_t rgb_len, int16_t *y, int16_t *co, int16_t *cg, uint64_t n_out);
 int alice_codec_ycocg_r_to_rgb(const int16_t *y, const int16_t *co, const int16_t *cg, uint64_t n, uint8_t *rgb, uint64_t rgb_len);

@@ -237,6 +237,39 @@ private:
     std::vector<uint8_t> in_;
 };
 
+class InterleavedRansEncoder {  // src/rans.rs:393-456 (opt-in 4-stream format)
+public:
+    static InterleavedRansEncoder new_() { return {}; }
+    void encode(const std::vector<uint8_t>& symbols, const FrequencyTable& table) { sym_ = symbols; table_ = table; }
+    std::vector<uint8_t> finish() {
+        uint64_t n = 0;
+        static const uint8_t empty = 0;
+        uint8_t* p = alice_codec_rans_encode_interleaved(sym_.empty() ? &empty : sym_.data(), sym_.size(), table_.cum_freq.data(),
+                                                         table_.freq.data(), &n);
+        if (!p) detail::raise();
+        return detail::take(p, n);
+    }
+private:
+    std::vector<uint8_t> sym_;
+    FrequencyTable table_ = FrequencyTable{};
+};
+
+class InterleavedRansDecoder {  // src/rans.rs:468-519
+public:
+    explicit InterleavedRansDecoder(std::vector<uint8_t> input) : in_(std::move(input)) {}
+    std::vector<uint8_t> decode_n(size_t n, const FrequencyTable& table) const {
+        std::vector<uint8_t> out(n);
+        static const uint8_t empty = 0;
+        uint8_t sink = 0;
+        detail::check(alice_codec_rans_decode_interleaved(in_.empty() ? &empty : in_.data(), in_.size(), table.cum_freq.data(),
+                                                          table.freq.data(), n, n ? out.data() : &sink));
+        return out;
+    }
+private:
+    std::vector<uint8_t> in_;
+};
+using SimdRansDecoder = InterleavedRansDecoder;  // src/rans.rs:531-666: same format, same symbols
+
 inline double psnr(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b) {
     if (a.size() != b.size()) return -1.0;
     static const uint8_t empty = 0;

@@ -284,6 +284,42 @@ def test_rans_streams(gpu_codec, oracle_mod):
         assert np.array_equal(gpu_codec.RansDecoder(data).decode_n(300, uni_g), oracle_mod.rans_decode(data, 300, uni_o))
 
 
+def test_interleaved_rans_streams(gpu_codec, oracle_mod):
+    """InterleavedRansEncoder / InterleavedRansDecoder (src/rans.rs:393-519): four chains on the GPU; the
+    reference's own round trips (src/rans.rs:745-780) plus every length residue."""
+    rng = np.random.default_rng(77)
+    for n in (0, 1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 66, 67, 1000, 4097, 70001):
+        sym = (rng.integers(0, 40, n) * (rng.random(n) < 0.4)).astype(np.uint8)
+        hist = np.bincount(sym, minlength=256).astype(np.uint32)
+        if n == 0:
+            hist[:] = 1
+        tg = gpu_codec.FrequencyTable.from_histogram(hist)
+        to = oracle_mod.FrequencyTable(hist)
+        enc = gpu_codec.InterleavedRansEncoder()
+        enc.encode(sym, tg)
+        got = enc.finish()
+        ref = oracle_mod.rans_encode(sym, to, interleaved=True)
+        assert got == ref, n
+        assert np.array_equal(gpu_codec.InterleavedRansDecoder(ref).decode_n(n, tg), oracle_mod.rans_decode(ref, n, to, interleaved=True)), n
+        if n >= 8:   # a prefix: the streams are walked round-robin from the start
+            assert np.array_equal(gpu_codec.SimdRansDecoder(ref).decode_n(n - 5, tg),
+                                  oracle_mod.rans_decode(ref, n - 5, to, interleaved=True)), n
+    # header counts that are not the encoder's: streams that run out are skipped (src/rans.rs:506-509)
+    sym = rng.integers(0, 6, 37).astype(np.uint8)
+    hist = np.bincount(sym, minlength=256).astype(np.uint32)
+    tg = gpu_codec.FrequencyTable.from_histogram(hist); to = oracle_mod.FrequencyTable(hist)
+    parts = [sym[0:3], sym[3:20], sym[20:21], sym[21:37]]
+    streams = [oracle_mod.rans_encode(p, to) for p in parts]
+    blob = b"".join(len(s).to_bytes(4, "little") for s in streams) + b"".join(len(p).to_bytes(4, "little") for p in parts) + b"".join(streams)
+    want = oracle_mod.rans_decode(blob, 37, to, interleaved=True)
+    assert np.array_equal(gpu_codec.InterleavedRansDecoder(blob).decode_n(37, tg), want)
+    assert np.array_equal(gpu_codec.InterleavedRansDecoder(blob).decode_n(20, tg), want[:20])
+    with pytest.raises(gpu_codec.CodecError):
+        gpu_codec.InterleavedRansDecoder(blob).decode_n(38, tg)      # the reference would spin forever
+    with pytest.raises(gpu_codec.CodecError):
+        gpu_codec.InterleavedRansDecoder(blob[:40]).decode_n(4, tg)  # the reference would index out of bounds
+
+
 def test_zero_frequency_symbol_is_reported(gpu_codec, oracle_mod):
     """A histogram whose table gives symbol 255 frequency 0: counts 3842 / 254 out of 4096 normalise to
     themselves, the 254 unused symbols take one slot each, so the sum is 4096 + 254 and the "fix" on the
