@@ -84,32 +84,25 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// In-register 1-D lifting of N consecutive samples (v[0] has even global index g0).
-// EDGE: g0 + k may fall outside [0, n); mirrors follow the reference at the true ends, array ends
-// clamp (their garbage stays inside the halo).  INVERSE applies the steps reversed with -coeff.
+// In-register 1-D lifting of N consecutive samples (v[0] has an even global index).  No boundary logic: the
+// tile kernels load through the symmetric extension (reflect_idx), and the two array ends simply reuse their
+// inner neighbour (that garbage stays inside the halo, which is never stored).  INVERSE applies the steps
+// reversed with -coeff (src/wavelet.rs:167-174).
 // ------------------------------------------------------------------------------------------------
-template <int N, int NS, bool EDGE, bool EXACT, bool INVERSE>
-__device__ __forceinline__ void lift_regs(int (&v)[N], const Coeffs& cf, int g0, int n) {
+template <int N, int NS, bool EXACT, bool INVERSE>
+__device__ __forceinline__ void lift_regs(int (&v)[N], const Coeffs& cf) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int k_step = INVERSE ? (NS - 1 - s) : s;
         const int c = INVERSE ? -cf.c[k_step] : cf.c[k_step];
         if ((k_step & 1) == 0) {  // predict: odd += d(even_left, even_right), src/wavelet.rs:184-196
 #pragma unroll
-            for (int k = 1; k < N; k += 2) {
-                int right;
-                if (k + 1 < N) right = (!EDGE || (g0 + k + 1 < n)) ? v[k + 1] : v[k - 1];
-                else right = v[k - 1];
-                v[k] = wadd(v[k], lift_delta<EXACT>(v[k - 1], right, c));
-            }
+            for (int k = 1; k < N; k += 2) v[k] = wadd(v[k], lift_delta<EXACT>(v[k - 1], (k + 1 < N) ? v[k + 1] : v[k - 1], c));
         } else {                  // update: even += d(odd_left, odd_right), src/wavelet.rs:205-216
 #pragma unroll
             for (int k = 0; k < N; k += 2) {
                 const int rgt = (k + 1 < N) ? v[k + 1] : v[k - 1];
-                int left;
-                if (k >= 1) left = (!EDGE || (g0 + k > 0)) ? v[k - 1] : rgt;
-                else left = rgt;
-                v[k] = wadd(v[k], lift_delta<EXACT>(left, rgt, c));
+                v[k] = wadd(v[k], lift_delta<EXACT>((k >= 1) ? v[k - 1] : rgt, rgt, c));
             }
         }
     }
@@ -195,9 +188,9 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             int ly[NL], lco[NL], lcg[NL];
 #pragma unroll
             for (int k = 0; k < NL; ++k) { ly[k] = y[K0 + k]; lco[k] = co[K0 + k]; lcg[k] = cg[K0 + k]; }
-            lift_regs<NL, NS, false, false, false>(ly, cf, 0, 0);
-            lift_regs<NL, NS, false, false, false>(lco, cf, 0, 0);
-            lift_regs<NL, NS, false, false, false>(lcg, cf, 0, 0);
+            lift_regs<NL, NS, false, false>(ly, cf);
+            lift_regs<NL, NS, false, false>(lco, cf);
+            lift_regs<NL, NS, false, false>(lcg, cf);
             // interior 16 samples -> LDS row r as packed i16 pairs (values stay below 2^13 after the row pass):
             // dword q of a row holds deinterleaved positions (2q, 2q+1); evens of segment s start at
             // position s*8, odds at 64 + s*8
@@ -227,7 +220,7 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             const int sh = (xq & 1) * 16;
 #pragma unroll
             for (int r = 0; r < ER; ++r) v[r] = (int)(short)(L[r * F_LP] >> sh);
-            lift_regs<ER, NS, false, false, false>(v, cf, 0, 0);
+            lift_regs<ER, NS, false, false>(v, cf);
             int16_t* out = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
 #pragma unroll
             for (int k = 0; k < F_TH; ++k) {
@@ -617,7 +610,7 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
                 const int yy = (gy & 1) * hh + (gy >> 1);
                 v[k] = (int)src[(size_t)yy * pw];
             }
-            lift_regs<ER, NS, false, EXACT, true>(v, cf, 0, 0);
+            lift_regs<ER, NS, EXACT, true>(v, cf);
             int* L = lds + (ch * ER) * LW + xq;
 #pragma unroll
             for (int k = 0; k < ER; ++k) L[k * LW] = v[k];
@@ -642,9 +635,9 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
                 const int q = (lx & 1) * ECh + (lx >> 1);
                 y[k] = L0[q]; co[k] = L1[q]; cg[k] = L2[q];
             }
-            lift_regs<NL, NS, false, EXACT, true>(y, cf, 0, 0);
-            lift_regs<NL, NS, false, EXACT, true>(co, cf, 0, 0);
-            lift_regs<NL, NS, false, EXACT, true>(cg, cf, 0, 0);
+            lift_regs<NL, NS, EXACT, true>(y, cf);
+            lift_regs<NL, NS, EXACT, true>(co, cf);
+            lift_regs<NL, NS, EXACT, true>(cg, cf);
             uint8_t out[I_SEG * 3];
 #pragma unroll
             for (int k = 0; k < I_SEG; ++k) {
@@ -730,19 +723,10 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
     const size_t plane = (size_t)d.pw * d.ph;
     const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
     dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
-    // ALICE_CODEC_SPLIT_HIST=1: histogram in a separate pass over the symbols instead of fused LDS atomics (A/B switch)
-    static const bool split_hist = getenv("ALICE_CODEC_SPLIT_HIST") != nullptr;
-#define ALICE_FWD_T(NS_, S1_, H_) hipLaunchKernelGGL((fwd_t_kernel<NS_, S1_, H_>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic)
-    if (ls.n == 4) {
-        if (split_hist) { if (step == 1) ALICE_FWD_T(4, true, false); else ALICE_FWD_T(4, false, false); }
-        else { if (step == 1) ALICE_FWD_T(4, true, true); else ALICE_FWD_T(4, false, true); }
-    } else {
-        if (split_hist) { if (step == 1) ALICE_FWD_T(2, true, false); else ALICE_FWD_T(2, false, false); }
-        else { if (step == 1) ALICE_FWD_T(2, true, true); else ALICE_FWD_T(2, false, true); }
-    }
+#define ALICE_FWD_T(NS_, S1_) hipLaunchKernelGGL((fwd_t_kernel<NS_, S1_, true>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic)
+    if (ls.n == 4) { if (step == 1) ALICE_FWD_T(4, true); else ALICE_FWD_T(4, false); }
+    else { if (step == 1) ALICE_FWD_T(2, true); else ALICE_FWD_T(2, false); }
 #undef ALICE_FWD_T
-    if (split_hist)
-        for (int c = 0; c < 3; ++c) launch_histogram(d_sym + (size_t)c * d.padded, d.padded, d_hist + c * 256, st);
     return true;
 }
 

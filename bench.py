@@ -98,7 +98,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "144")),
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "152")),
                     help="1080p x 64 chunks in flight per GPU (3 rANS chains each)")
     ap.add_argument("--separate-output", action="store_true",
                     help="decode into a caller-owned RGB buffer instead of the batch's own storage (one more RGB-sized buffer per chunk)")
@@ -125,6 +125,10 @@ def main() -> None:
 
     B = args.chunks
     px_chunk = W * H * F
+    # rehearsal switch: hold this many extra GB, e.g. the blobs rank 0 of an 8-GPU run would receive, to check the fit
+    ballast = None
+    if os.environ.get("ALICE_BENCH_BALLAST_GB"):
+        ballast = torch.empty(int(float(os.environ["ALICE_BENCH_BALLAST_GB"]) * 1e9), dtype=torch.uint8, device=dev)
     rgb = torch.empty((B, F, H, W, 3), dtype=torch.uint8, device=dev)
     for i in range(B):
         rgb[i] = synth_chunk(dev, rank * B + i)
@@ -184,6 +188,8 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    print(f"[bench] rank {rank}: HBM free {free_b / 1e9:.1f} GB of {total_b / 1e9:.1f} GB after the timed steps", file=sys.stderr)
     if rank == 0:
         ms = {k: v / max(n_acc, 1) for k, v in stage_acc.items()}  # per step, whole batch of this rank
         value = 2.0 * args.steps * world * B * px_chunk / elapsed / 1e6
