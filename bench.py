@@ -240,6 +240,21 @@ def main() -> None:
                 result["roofline_inverse"]["traffic"] = tj.get("inverse_transform_hbm_bytes_per_launch")
             except Exception:
                 pass
+        # The transform kernels are bound by integer VALU issue, not by HBM: report the
+        # VALU view beside the HBM one.  Lane-operations per pixel are PMC counts (SQ_INSTS_VALU x 64,
+        # profiles/sq_counters.json); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
+        sq_file = os.path.join(ROOT, "profiles", "sq_counters.json")
+        if os.path.exists(sq_file):
+            try:
+                pk = json.load(open(sq_file))["per_kernel"]
+                peak = 256 * 4 * 16 * 2.4e9
+                for key, pref, secs in (("roofline", "fwd_", fwd_s), ("roofline_inverse", "inv_", inv_s)):
+                    ops = sum(v.get("valu_lane_ops_per_pixel", 0.0) for k, v in pk.items() if pref in k)
+                    if ops > 0:
+                        result[key]["valu"] = {"lane_ops_per_pixel": round(ops, 1), "achieved_tera_lane_ops": round(ops * px_chunk / secs / 1e12, 2),
+                                               "peak_tera_lane_ops": round(peak / 1e12, 2), "frac": round(ops * px_chunk / secs / peak, 4)}
+            except Exception:
+                pass
         if world == 1 and args.cpu_frames > 0:
             fr = min(args.cpu_frames, F)
             sample = rgb[0, :fr].contiguous().cpu().numpy().reshape(-1)

@@ -6,6 +6,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/final
+rm -rf $OUT
 mkdir -p $OUT
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --chunks 4 --steps 2 --warmup 1 --cpu-frames 0 > $OUT/bench_chunks4_profiled.json 2> $OUT/stats.log
 echo "stats done"

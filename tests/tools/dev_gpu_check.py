@@ -1,6 +1,6 @@
 """Developer check on a GPU box: HIP path vs oracle on a few shapes (not a test; see tests/)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle as o
 import alice_codec_amd as a

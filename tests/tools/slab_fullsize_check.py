@@ -2,7 +2,7 @@
 `world` ranks share cuda:0 and exchange over gloo.  Compares the sharded `.alc` with the single-GPU encode of the
 whole chunk (and, with --oracle, with the CPU oracle), and the sharded decode with the single-GPU decode.
 
-  python scripts/slab_fullsize_check.py W H F QUALITY WAVELET WORLD [--oracle]
+  python tests/tools/slab_fullsize_check.py W H F QUALITY WAVELET WORLD [--oracle]
 
 Prints one JSON line per phase (progress) and a final summary on rank 0."""
 import hashlib
@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def synth_rows(dev, w, h, f, r0, r1):
