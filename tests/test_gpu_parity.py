@@ -101,6 +101,32 @@ def test_every_frame_count_through_the_streaming_temporal_pass(gpu_codec, oracle
         assert np.array_equal(gpu_codec.FrameDecoder().decode(chunk), oracle_mod.decode(ref)), f
 
 
+def test_seeded_random_shapes(gpu_codec, oracle_mod):
+    """150 seeded random (shape, quality, wavelet, content) cases against the oracle: tile borders, odd sizes,
+    shapes below the tile kernels' minimum (generic path), every content class."""
+    rng = np.random.default_rng(20260)
+    for case in range(150):
+        if case < 120:
+            w = int(rng.integers(1, 160)); h = int(rng.integers(1, 110)); f = int(rng.integers(1, 20))
+        else:   # several tiles in both directions, interior and border instances
+            w = int(rng.integers(260, 700)); h = int(rng.integers(90, 420)); f = int(rng.integers(2, 12))
+        q = int(rng.integers(0, 101)); k = int(rng.integers(0, 3))
+        kind = case % 4
+        if kind == 0:
+            rgb = rng.integers(0, 256, w * h * f * 3, dtype=np.uint8)
+        elif kind == 1:
+            rgb = smooth_rgb(w, h, f, seed=case)
+        elif kind == 2:
+            rgb = oracle_mod.make_gradient(w, h, f)
+        else:
+            rgb = np.full(w * h * f * 3, int(rng.integers(0, 256)), dtype=np.uint8)
+        ref = oracle_mod.encode(rgb, w, h, f, q, k)
+        chunk = gpu_codec.FrameEncoder.with_wavelet(q, gpu_codec.WaveletType(k)).encode(rgb, w, h, f)
+        got = chunk.to_bytes()
+        assert got == ref, (case, w, h, f, q, k, first_diff(got, ref))
+        assert np.array_equal(gpu_codec.FrameDecoder().decode(chunk), oracle_mod.decode(ref)), (case, w, h, f, q, k)
+
+
 def test_empty_chunk(gpu_codec):  # src/pipeline.rs:738-743, 764-769
     c = gpu_codec.FrameEncoder(50).encode(np.zeros(0, np.uint8), 0, 0, 0)
     assert c.compressed_size() == 0 and gpu_codec.FrameDecoder().decode(c).size == 0
