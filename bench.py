@@ -100,11 +100,17 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("ALICE_BENCH_CHUNKS", "152")),
                     help="1080p x 64 chunks in flight per GPU (3 rANS chains each)")
+    ap.add_argument("--wavelet", choices=["cdf97", "cdf53", "haar"], default="cdf97",
+                    help="cdf97 is the BASELINE metric; cdf53 = BASELINE.json configs[1] (the roofline fields then describe that run)")
+    ap.add_argument("--quality", type=int, default=80)
     ap.add_argument("--separate-output", action="store_true",
                     help="decode into a caller-owned RGB buffer instead of the batch's own storage (one more RGB-sized buffer per chunk)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of chunk 0 in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
+    global QUALITY, WAVELET
+    QUALITY = args.quality
+    WAVELET = {"cdf97": ac.WaveletType.Cdf97, "cdf53": ac.WaveletType.Cdf53, "haar": ac.WaveletType.Haar}[args.wavelet]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -199,13 +205,15 @@ def main() -> None:
         dec_chain_s = ms["rans_decode"] / 1e3
         payload_bpp = float(sizes.sum() - 3138 * B) / (B * px_chunk)
         result = {
-            "metric": "Mpixels/s encode+decode, 1080p x 64 CDF9/7 q=80; bit-exact vs CPU",
+            "metric": ("Mpixels/s encode+decode, 1080p x 64 CDF9/7 q=80; bit-exact vs CPU" if (args.wavelet, QUALITY) == ("cdf97", 80)
+                       else f"Mpixels/s encode+decode, 1080p x 64 {args.wavelet} q={QUALITY}; bit-exact vs CPU"),
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "1920x1080x64 RGB chunks, CDF 9/7, q=80 (BASELINE.json configs[2]); "
-                                   f"{B} independent chunks in flight per GPU = {3 * B} single-stream rANS chains",
-                       "chunks_per_gpu": B, "wavelet": "cdf97", "quality": QUALITY,
+            "config": {"workload": ("1920x1080x64 RGB chunks, CDF 9/7, q=80 (BASELINE.json configs[2]); " if (args.wavelet, QUALITY) == ("cdf97", 80)
+                                    else f"1920x1080x64 RGB chunks, {args.wavelet}, q={QUALITY} (not the headline configuration); ")
+                                   + f"{B} independent chunks in flight per GPU = {3 * B} single-stream rANS chains",
+                       "chunks_per_gpu": B, "wavelet": args.wavelet, "quality": QUALITY,
                        "parallelism": f"chunk-parallel x{world}" + (" + RCCL gather of .alc blobs on rank 0" if world > 1 else "")},
             "encode_mpix_s": round(world * B * px_chunk / ((ms["forward_transform"] + ms["rans_table"] + ms["rans_encode"] + ms["assemble"]) / 1e3) / 1e6, 2),
             "decode_mpix_s": round(world * B * px_chunk / ((ms["rans_decode"] + ms["inverse_transform"]) / 1e3) / 1e6, 2),
