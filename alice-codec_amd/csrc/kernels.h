@@ -45,8 +45,10 @@ void launch_merge4(const uint8_t* d_in, uint64_t stride, const uint64_t have[4],
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
 
 // ---- transform.hip (pipeline-specialised: RGB <-> u8 symbols) ----
-// mid: int32 [3][pf][ph][pw] scratch for one chunk.  hist: uint32 [3][256], zeroed by the caller.
-// Returns false when the shape needs the generic path (pf > 64).
+// mid: scratch of 3 * padded int32 for one chunk (used as i16 by the forward path).  hist: uint32 [3][256],
+// zeroed by the caller.  Returns false when the shape needs the generic path: a padded width or height
+// below 6 (the tile kernels read their halo through one reflection), a frame of more than 2^30 samples
+// (32-bit offsets inside a frame), or more tiles than a 1-D grid holds.
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
                               int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st);
 // steps/dead zones per channel come from the chunk header.  exact = 64-bit lifting products.

@@ -77,7 +77,7 @@ def test_encode_decode_matches_oracle(gpu_codec, oracle_mod, w, h, f, q, k):
         assert np.array_equal(dec, oracle_mod.decode(ref)), name
 
 
-def test_more_than_64_frames_uses_generic_kernels(gpu_codec, oracle_mod):
+def test_more_than_64_frames(gpu_codec, oracle_mod):
     """The reference CLI encodes a whole file as one chunk (src/bin/main.rs:117-122): any frame count."""
     for w, h, f, q, k in ((20, 12, 66, 80, 1), (16, 16, 131, 90, 0)):
         rgb = smooth_rgb(w, h, f, seed=5)
