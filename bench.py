@@ -79,6 +79,19 @@ def cpu_baseline(sample_rgb: np.ndarray, frames: int, gpu_alc: bytes, gpu_dec: n
     t1 = time.perf_counter()
     dec = oracle.decode(alc, _lib=lib)
     t2 = time.perf_counter()
+    # non-reference variant (SURVEY.md section 8d ii): Y, Co, Cg on three threads, what a rayon::join would give
+    par3 = None
+    try:
+        t3 = time.perf_counter()
+        alc3 = oracle.encode(sample_rgb, W, H, frames, QUALITY, int(WAVELET), _lib=lib, three_threads=True)
+        t4 = time.perf_counter()
+        dec3 = oracle.decode(alc3, _lib=lib, three_threads=True)
+        t5 = time.perf_counter()
+        par3 = {"value": round(2 * W * H * frames / (t5 - t3) / 1e6, 3), "unit": "Mpix/s", "cores": 3,
+                "note": "NOT the reference, which is single-threaded: the same port with the three channels on three threads",
+                "same_bytes": bool(alc3 == alc and np.array_equal(dec3, dec))}
+    except Exception:
+        pass
     px = W * H * frames
     try:
         model = subprocess.check_output("lscpu | grep 'Model name' | head -1", shell=True, text=True).split(":", 1)[1].strip()
@@ -86,10 +99,11 @@ def cpu_baseline(sample_rgb: np.ndarray, frames: int, gpu_alc: bytes, gpu_dec: n
         model = "unknown"
     return {
         "value": round(2 * px / (t2 - t0) / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-        "sample": f"{W}x{H}x{frames} (first {frames} frames of chunk 0), CDF 9/7 q=80, encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s",
+        "sample": f"{W}x{H}x{frames} (first {frames} frames of chunk 0), {WAVELET.name} q={QUALITY}, encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s",
         "encode_mpix_s": round(px / (t1 - t0) / 1e6, 3), "decode_mpix_s": round(px / (t2 - t1) / 1e6, 3),
         "host_cpu": model, "host_threads_available": os.cpu_count(),
         "gpu_bit_exact_on_sample": bool(gpu_alc == alc and np.array_equal(gpu_dec, dec)),
+        "three_thread_variant": par3,
     }
 
 

@@ -70,7 +70,7 @@ def build(force: bool = False, so_path: str | None = None, cflags: str | None = 
     if force or stale:
         os.makedirs(os.path.dirname(so), exist_ok=True)
         flags = (cflags or "-O3 -fPIC -std=c11").split()
-        subprocess.check_call(["gcc", *flags, "-shared", "-o", so, src, "-lm"])
+        subprocess.check_call(["gcc", *flags, "-pthread", "-shared", "-o", so, src, "-lm"])
     return so
 
 
@@ -122,6 +122,8 @@ def _bind(lib):
     lib.ao_encode.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8,
                               C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     lib.ao_decode.argtypes = [_u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    lib.ao_encode_par3.argtypes = lib.ao_encode.argtypes
+    lib.ao_decode_par3.argtypes = lib.ao_decode.argtypes
     lib.ao_encode_symbols.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint8, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     lib.ao_psnr.argtypes = [_u8p, _u8p, C.c_size_t]
@@ -337,25 +339,27 @@ def quality_to_step(q: int) -> int:
 # ---- pipeline ----------------------------------------------------------------------
 
 def encode(rgb, width: int, height: int, frames: int, quality: int, wavelet: int = CDF53,
-           _lib=None) -> bytes:
-    """FrameEncoder::with_wavelet(quality, wavelet).encode(rgb, w, h, f).to_bytes()."""
+           _lib=None, three_threads: bool = False) -> bytes:
+    """FrameEncoder::with_wavelet(quality, wavelet).encode(rgb, w, h, f).to_bytes().
+    three_threads: the non-reference variant with Y, Co, Cg on three threads (same bytes)."""
     L = _lib or lib()
     r = _u8(rgb).reshape(-1)
     out = _u8p(); n = C.c_size_t()
-    _check(L.ao_encode(_ptr(r, _u8p), r.size, width, height, frames, quality, wavelet,
-                       C.byref(out), C.byref(n)))
+    fn = L.ao_encode_par3 if three_threads else L.ao_encode
+    _check(fn(_ptr(r, _u8p), r.size, width, height, frames, quality, wavelet,
+              C.byref(out), C.byref(n)))
     try:
         return _copy_out(out, n.value).tobytes()
     finally:
         L.ao_free(C.cast(out, C.c_void_p))
 
 
-def decode(alc, _lib=None) -> np.ndarray:
+def decode(alc, _lib=None, three_threads: bool = False) -> np.ndarray:
     """FrameDecoder::new().decode(&EncodedChunk::from_bytes(alc)?)."""
     L = _lib or lib()
     d = _u8(alc).reshape(-1)
     out = _u8p(); n = C.c_size_t()
-    _check(L.ao_decode(_ptr(d, _u8p), d.size, C.byref(out), C.byref(n)))
+    _check((L.ao_decode_par3 if three_threads else L.ao_decode)(_ptr(d, _u8p), d.size, C.byref(out), C.byref(n)))
     try:
         return _copy_out(out, n.value)
     finally:

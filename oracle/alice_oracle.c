@@ -813,6 +813,149 @@ int ao_decode(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len
     return AO_OK;
 }
 
+/* ---- NOT the reference: the same encode/decode with the three channels on three threads --------------------
+ * The reference is single-threaded (it has no rayon path).  These two functions are what
+ * a `rayon::join` over Y / Co / Cg would give and exist only so that bench.py can time that hypothetical
+ * variant beside the faithful one (variant ii).  Same stage functions, same bytes. */
+#include <pthread.h>
+
+typedef struct {
+    /* encode */
+    const int16_t *plane; size_t w, h, f, pw, ph, pf, padded; int wavelet; int32_t step;
+    channel_header *hdr; uint8_t *stream; size_t len;
+    /* decode */
+    const uint8_t *comp; size_t clen; int16_t *out_plane;
+    int rc;
+} chan_job;
+
+static void *enc_channel(void *arg) {
+    chan_job *j = (chan_job *)arg;
+    j->rc = AO_ERR_NOMEM;
+    int32_t *buf = pad_channel_to_i32(j->plane, j->w, j->h, j->f, j->pw, j->ph, j->pf);
+    int32_t *qbuf = (int32_t *)malloc(j->padded * sizeof(int32_t));
+    uint8_t *sym = (uint8_t *)malloc(j->padded);
+    if (buf && qbuf && sym) {
+        ao_wavelet3d_forward(j->wavelet, buf, j->pw, j->ph, j->pf);
+        ao_quantize_buffer(j->step, j->step, buf, qbuf, j->padded);
+        ao_to_symbols(qbuf, sym, j->padded);
+        ao_build_histogram(sym, j->padded, j->hdr->histogram);
+        ao_freq_table tbl;
+        j->rc = ao_freq_table_from_histogram(j->hdr->histogram, 256, &tbl);
+        if (j->rc == AO_OK) j->rc = ao_rans_encode(sym, j->padded, &tbl, &j->stream, &j->len);
+        ao_freq_table_free(&tbl);
+        j->hdr->compressed_len = (uint32_t)j->len;
+        j->hdr->quant_step = j->step; j->hdr->quant_dead_zone = j->step; j->hdr->num_symbols = (uint32_t)j->padded;
+    }
+    free(buf); free(qbuf); free(sym);
+    return NULL;
+}
+
+int ao_encode_par3(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t height, uint32_t frames,
+                   uint8_t quality, int wavelet, uint8_t **out, size_t *out_len) {
+    size_t w = width, h = height, f = frames, n_pixels;
+    int rc = checked_pixel_count(w, h, f, &n_pixels);
+    if (rc) return rc;
+    if (n_pixels == 0 || w == 0 || h == 0 || rgb_len != n_pixels * 3)
+        return ao_encode(rgb, rgb_len, width, height, frames, quality, wavelet, out, out_len);
+    int16_t *pl[3];
+    for (int c = 0; c < 3; ++c) pl[c] = (int16_t *)malloc(n_pixels * sizeof(int16_t));
+    if (!pl[0] || !pl[1] || !pl[2]) { for (int c = 0; c < 3; ++c) free(pl[c]); return AO_ERR_NOMEM; }
+    ao_rgb_bytes_to_ycocg_r(rgb, rgb_len, pl[0], pl[1], pl[2], n_pixels);
+    size_t pw, ph, pf;
+    padded_dims(w, h, f, &pw, &ph, &pf);
+    channel_header hdr[3];
+    chan_job job[3];
+    pthread_t th[3];
+    for (int c = 0; c < 3; ++c) {
+        memset(&hdr[c], 0, sizeof(hdr[c]));
+        memset(&job[c], 0, sizeof(job[c]));
+        job[c].plane = pl[c]; job[c].w = w; job[c].h = h; job[c].f = f; job[c].pw = pw; job[c].ph = ph; job[c].pf = pf;
+        job[c].padded = pw * ph * pf; job[c].wavelet = wavelet; job[c].step = ao_quality_to_step(quality); job[c].hdr = &hdr[c];
+        pthread_create(&th[c], NULL, enc_channel, &job[c]);
+    }
+    for (int c = 0; c < 3; ++c) { pthread_join(th[c], NULL); free(pl[c]); if (job[c].rc) rc = job[c].rc; }
+    if (rc) { for (int c = 0; c < 3; ++c) free(job[c].stream); return rc; }
+    size_t total = FIXED_HEADER_BYTES + 3 * CHANNEL_HEADER_BYTES + job[0].len + job[1].len + job[2].len;
+    uint8_t *buf = (uint8_t *)malloc(total);
+    if (!buf) { for (int c = 0; c < 3; ++c) free(job[c].stream); return AO_ERR_NOMEM; }
+    write_header(buf, wavelet, width, height, frames, hdr);
+    size_t off = FIXED_HEADER_BYTES + 3 * CHANNEL_HEADER_BYTES;
+    for (int c = 0; c < 3; ++c) { if (job[c].len) memcpy(buf + off, job[c].stream, job[c].len); off += job[c].len; free(job[c].stream); }
+    *out = buf; *out_len = total;
+    return AO_OK;
+}
+
+static void *dec_channel(void *arg) {
+    chan_job *j = (chan_job *)arg;
+    j->rc = AO_ERR_NOMEM;
+    uint8_t *symbols = (uint8_t *)malloc(j->padded);
+    int32_t *qbuf = (int32_t *)malloc(j->padded * sizeof(int32_t));
+    int32_t *buf = (int32_t *)malloc(j->padded * sizeof(int32_t));
+    if (symbols && qbuf && buf) {
+        ao_freq_table tbl;
+        j->rc = ao_freq_table_from_histogram(j->hdr->histogram, 256, &tbl);
+        if (j->rc == AO_OK) {
+            ao_rans_decode(j->comp, j->clen, j->padded, &tbl, symbols);
+            ao_freq_table_free(&tbl);
+            ao_from_symbols(symbols, qbuf, j->padded);
+            ao_dequantize_buffer(j->hdr->quant_step, qbuf, buf, j->padded);
+            ao_wavelet3d_inverse(j->wavelet, buf, j->pw, j->ph, j->pf);
+            for (size_t t = 0; t < j->f; ++t)
+                for (size_t row = 0; row < j->h; ++row)
+                    for (size_t col = 0; col < j->w; ++col)
+                        j->out_plane[t * j->w * j->h + row * j->w + col] =
+                            (int16_t)(uint16_t)(uint32_t)buf[t * j->pw * j->ph + row * j->pw + col];
+        }
+    }
+    free(symbols); free(qbuf); free(buf);
+    return NULL;
+}
+
+/* valid, non-empty chunks only (everything else goes through ao_decode, which carries the validation) */
+int ao_decode_par3(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len) {
+    size_t hdr_len = FIXED_HEADER_BYTES + 3 * CHANNEL_HEADER_BYTES;
+    if (alc_len < hdr_len || memcmp(alc, "ALCC", 4) != 0 || alc[4] != 1 || alc[5] > 2) return ao_decode(alc, alc_len, rgb, rgb_len);
+    int wavelet = alc[5];
+    size_t w = get_u32le(alc + 6), h = get_u32le(alc + 10), f = get_u32le(alc + 14), n_pixels;
+    if (checked_pixel_count(w, h, f, &n_pixels) || n_pixels == 0) return ao_decode(alc, alc_len, rgb, rgb_len);
+    size_t pw, ph, pf;
+    padded_dims(w, h, f, &pw, &ph, &pf);
+    channel_header hdr[3];
+    size_t off = FIXED_HEADER_BYTES, total = 0;
+    for (int c = 0; c < 3; ++c) {
+        hdr[c].compressed_len = get_u32le(alc + off); off += 4;
+        hdr[c].quant_step = (int32_t)get_u32le(alc + off); off += 4;
+        hdr[c].quant_dead_zone = (int32_t)get_u32le(alc + off); off += 4;
+        hdr[c].num_symbols = get_u32le(alc + off); off += 4;
+        for (int k = 0; k < 256; ++k) { hdr[c].histogram[k] = get_u32le(alc + off); off += 4; }
+        total += hdr[c].compressed_len;
+        if ((size_t)hdr[c].num_symbols != pw * ph * pf) return ao_decode(alc, alc_len, rgb, rgb_len);
+    }
+    if (alc_len < off + total) return ao_decode(alc, alc_len, rgb, rgb_len);
+    int16_t *pl[3];
+    uint8_t *out = (uint8_t *)malloc(n_pixels * 3);
+    for (int c = 0; c < 3; ++c) pl[c] = (int16_t *)calloc(n_pixels, sizeof(int16_t));
+    if (!out || !pl[0] || !pl[1] || !pl[2]) { free(out); for (int c = 0; c < 3; ++c) free(pl[c]); return AO_ERR_NOMEM; }
+    chan_job job[3];
+    pthread_t th[3];
+    size_t doff = 0;
+    for (int c = 0; c < 3; ++c) {
+        memset(&job[c], 0, sizeof(job[c]));
+        job[c].w = w; job[c].h = h; job[c].f = f; job[c].pw = pw; job[c].ph = ph; job[c].pf = pf; job[c].padded = pw * ph * pf;
+        job[c].wavelet = wavelet; job[c].hdr = &hdr[c]; job[c].comp = alc + off + doff; job[c].clen = hdr[c].compressed_len;
+        job[c].out_plane = pl[c];
+        doff += hdr[c].compressed_len;
+        pthread_create(&th[c], NULL, dec_channel, &job[c]);
+    }
+    int rc = AO_OK;
+    for (int c = 0; c < 3; ++c) { pthread_join(th[c], NULL); if (job[c].rc) rc = job[c].rc; }
+    if (rc == AO_OK) rc = ao_ycocg_r_to_rgb_bytes(pl[0], pl[1], pl[2], n_pixels, out, n_pixels * 3);
+    for (int c = 0; c < 3; ++c) free(pl[c]);
+    if (rc) { free(out); return rc; }
+    *rgb = out; *rgb_len = n_pixels * 3;
+    return AO_OK;
+}
+
 /* src/metrics.rs:16-63 mse + psnr (sequential f64 sum; libm log10) */
 double ao_psnr(const uint8_t *a, const uint8_t *b, size_t len) {
     if (len == 0) return INFINITY;

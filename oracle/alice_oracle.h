@@ -119,6 +119,11 @@ int ao_encode(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t heigh
               uint8_t quality, int wavelet, uint8_t **out, size_t *out_len);
 /* FrameDecoder::new().decode(EncodedChunk::from_bytes(..)); *rgb malloc'ed */
 int ao_decode(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len);
+/* NOT the reference (it is single-threaded): the same two calls with Y, Co, Cg on three threads -- the hypothetical
+ * "rayon::join" variant that bench.py times beside the faithful one.  Byte-identical results. */
+int ao_encode_par3(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t height, uint32_t frames,
+                   uint8_t quality, int wavelet, uint8_t **out, size_t *out_len);
+int ao_decode_par3(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len);
 /* encode front half only: per-channel u8 symbols (3 * padded_pixels, channel-major) */
 int ao_encode_symbols(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t height,
                       uint32_t frames, uint8_t quality, int wavelet, uint8_t **symbols,

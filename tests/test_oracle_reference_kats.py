@@ -311,3 +311,15 @@ def test_oracle_matches_golden(oracle_mod, path):
     alc = oracle_mod.encode(g["rgb"], int(g["w"]), int(g["h"]), int(g["f"]), int(g["quality"]), int(g["wavelet"]))
     assert alc == g["alc"].tobytes()
     assert np.array_equal(oracle_mod.decode(alc), g["decoded"])
+
+
+def test_three_thread_variant_is_byte_identical():
+    """ao_encode_par3 / ao_decode_par3 (not the reference: the hypothetical per-channel threading that bench.py
+    times as a second CPU baseline) must produce the oracle's own bytes."""
+    import oracle as o
+    rng = np.random.default_rng(5)
+    for (w, h, f, q, k) in [(64, 48, 8, 80, 1), (33, 21, 5, 90, 0), (4, 4, 2, 90, 1), (1, 1, 1, 100, 0), (0, 0, 0, 80, 1)]:
+        rgb = rng.integers(0, 256, w * h * f * 3, dtype=np.uint8)
+        a = o.encode(rgb, w, h, f, q, k)
+        assert o.encode(rgb, w, h, f, q, k, three_threads=True) == a
+        assert np.array_equal(o.decode(a), o.decode(a, three_threads=True))
