@@ -71,6 +71,7 @@ static_assert(sizeof(RansEncEntry) == 32, "RansEncEntry must be 32 bytes");
 // flags produced by rans_table_kernel
 constexpr uint32_t kTableNeedsGeneric = 1u;   // a symbol present in the data has freq > 4096
 constexpr uint32_t kTableDiverges = 2u;       // a symbol present in the data has freq == 0
+constexpr uint32_t kTableVerified = 16u;      // built from the data's own histogram: the two flags above are authoritative
 
 struct RansTable {
     RansEncEntry enc[256];

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void rans_table_kernel(const uint32_t* __restr
     __syncthreads();
     if (fl) atomicOr(&flags_sh, fl);
     __syncthreads();
-    if (s == 0) tables[chain].flags = flags_sh;
+    if (s == 0) tables[chain].flags = flags_sh | kTableVerified;
 }
 
 // Table from explicit (cum, freq) arrays -- stage-level API (FrequencyTable handle).
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         tab_b[s] = make_uint4((uint32_t)e.g, e.cbias, e.freq, e.cum);
     }
 
+    const bool table_clean = tbl->flags == kTableVerified;  // uniform
     uint32_t x = kRansL;  // RansEncoder::new, src/rans.rs:249-254
     const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
     unsigned long long written = 0ull;
@@ -275,6 +276,40 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         // no memory), the table rows of block b+1 and the symbols of block b+2 are in flight from LDS.
         uint32_t sym1 = sym_of(1);
         BlockParams nxt = params_of(sym_of(0));
+        // Full tile, table known to hold only frequencies 1..4096 for the symbols that occur, room for the worst
+        // case of the whole tile: no per-block activity mask, table check or capacity test; the state is carried
+        // from block to block inside the vector unit (lane 0 <- lane 63 by a wave rotate) instead of through
+        // two readlanes and a scalar add.
+        if (table_clean && valid == kEncTile && written + 2ull * kEncTile + 4ull + 320ull <= cap) {
+            uint32_t xin = x;
+#pragma unroll 2
+            for (int b = 0; b < kEncTile / 64; ++b) {
+                const BlockParams curp = nxt;
+                nxt = params_of(sym1);
+                sym1 = sym_of(b + 2);
+                const uint32_t xmax = curp.ea.x, xmax8 = curp.ea.y, rcp = curp.ea.z, rsh = curp.ea.w;
+                const int32_t g = (int32_t)curp.eb.x;
+                const uint32_t cbias = curp.eb.y;
+                uint32_t xout = 0u;
+                const uint32_t cprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cbias, 0x138, 0xf, 0xf, true);
+                ripple64(xin, xout, xmax, xmax8, rcp, rsh, g, cprev);
+                const bool c1 = xin >= xmax;
+                const bool c2 = xin >= xmax8;
+                const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
+                const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)) +
+                                     __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+                // one uniform base 320 bytes ahead of the write position; real bytes at 319 - off and 318 - off,
+                // lanes with nothing to emit write their own byte of the 64 at the bottom (not yet written stream space)
+                uint8_t* const base = out_end - written - 320ull;
+                base[c1 ? 319u - off : (uint32_t)lane] = (uint8_t)(xin & 0xFFu);
+                base[c2 ? 318u - off : (uint32_t)lane] = (uint8_t)((xin >> 8) & 0xFFu);
+                written += (unsigned long long)((uint32_t)__popcll(b1) + (uint32_t)__popcll(b2));
+                // wave_ror:1 -- lane 0 of the next block's xin receives xout[63] + cbias[63]
+                xin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(xout + cbias), 0x13C, 0xf, 0xf, false);
+            }
+            x = (uint32_t)__builtin_amdgcn_readlane((int)xin, 0);
+            continue;
+        }
         for (int b = 0; b < nblocks; ++b) {
             const BlockParams curp = nxt;
             nxt = params_of(sym1);
