@@ -105,6 +105,36 @@ e("s_sub_u32 %[po], s70, s71")
 e("s_mov_b32 %[xo], s61")
 e("s_waitcnt lgkmcnt(0)")
 
+# ---- "dry" tile: the stream is exhausted (pos >= len), so the reference's refill loop reads nothing any more
+# (src/rans.rs:365-368) and the state simply evolves: the same lookup and update, no window, no shift.
+D = []
+def d(s): D.append(s)
+for r in range(64):
+    d(f"ds_read_b32 v{64 + r}, %[ta] offset:{256 * r}")
+for r in range(64):
+    d(f"ds_read_b32 v{128 + r}, %[tb] offset:{256 * r}")
+d("s_mov_b32 s61, %[xi]")
+d("s_mov_b32 s74, %[nb]")
+d("s_waitcnt lgkmcnt(0)")
+d("2:")
+for lane in range(64):
+    d("s_bfe_u32 s76, s61, 0x60006")
+    d("s_set_gpr_idx_on s76, 0x1")
+    d("v_readlane_b32 s67, v64, s61")
+    d("v_readlane_b32 s69, v128, s61")
+    d(f"v_writelane_b32 v{REC}, s61, {lane}")
+    d("s_mul_hi_u32 s70, s67, s61")
+    d("s_add_u32 s61, s70, s69")
+d("s_set_gpr_idx_off")
+d(f"ds_write_b16 %[ra], v{REC}")
+d("v_add_u32_e32 %[ra], 0x80, %[ra]")
+d("s_sub_u32 s74, s74, 1")
+d("s_cmp_lg_u32 s74, 0")
+d("s_cbranch_scc1 2b")
+d("s_mov_b32 %[xo], s61")
+d("s_waitcnt lgkmcnt(0)")
+dry_clob = ["memory", "scc", "m0", "s61", "s67", "s69", "s70", "s74", "s76"] + [f"v{r}" for r in range(64, 192)] + [f"v{REC}"]
+
 clob = ["memory", "scc", "m0"] + [f"s{i}" for i in range(60, 77)] + [f"s{80 + c}" for c in range(21)]
 clob += [f"v{r}" for r in range(64, REC + 1)]
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rans_decode_tile.inc")
@@ -115,4 +145,9 @@ with open(out, "w") as f:
         f.write(f'    "{s}\\n\\t" \\\n')
     f.write('    ""\n')
     f.write("#define ALICE_DEC_TILE_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + "\n")
+    f.write("#define ALICE_DEC_DRY_TILE_ASM \\\n")
+    for s in D:
+        f.write(f'    "{s}\\n\\t" \\\n')
+    f.write('    ""\n')
+    f.write("#define ALICE_DEC_DRY_TILE_CLOBBERS " + ", ".join(f'"{c}"' for c in dry_clob) + "\n")
 print("wrote", out, len(L), "asm lines")

@@ -431,6 +431,18 @@ __device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, uint32
     pos = po;
 }
 
+// The same lookup and update with the stream exhausted: nothing is shifted in any more (src/rans.rs:365-368 reads
+// no byte once pos == len), the state just evolves.  Needs a table without a frequency of 4096 (its F' encoding is
+// only right for x >= 1, and a dry state may reach 0).
+__device__ __forceinline__ void dec_tile_dry(uint32_t& x, uint32_t ftab_addr, uint32_t btab_addr, uint32_t rec_addr, uint32_t nblk) {
+    uint32_t xo;
+    asm volatile(ALICE_DEC_DRY_TILE_ASM
+                 : [xo] "=&s"(xo), [ra] "+v"(rec_addr)
+                 : [xi] "s"(x), [nb] "s"(nblk), [ta] "v"(ftab_addr), [tb] "v"(btab_addr)
+                 : ALICE_DEC_DRY_TILE_CLOBBERS);
+    x = xo;
+}
+
 __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* __restrict__ descs,
                                                          RansResult* __restrict__ results) {
     // x' = freq * (x >> 12) + slot - cum is evaluated as umulhi(F', x) + B' with F' = freq << 20 and
@@ -454,8 +466,10 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         else { fo = f << 20; bo = (s - c) - ((f * s) >> kProbBits); }
     };
     // cum_to_sym is zero-initialised (src/rans.rs:135): default every slot to symbol 0
+    bool big_freq;   // some symbol has freq >= 4096 (uniform)
     {
         const uint32_t f0 = d.table->enc[0].freq, c0 = d.table->enc[0].cum;
+        bool big = f0 >= kProbScale;
         for (int s = lane; s < (int)kProbScale; s += 64) {
             c2s[s] = 0;
             entry(f0, c0, (uint32_t)s, ftab[s], btab[s]);
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         for (int k = 0; k < 4; ++k) {
             const int sym = lane * 4 + k;
             const uint32_t f = d.table->enc[sym].freq, c = d.table->enc[sym].cum;
+            big |= f >= kProbScale && c < kProbScale;   // only an entry that owns slots matters (the wrapped symbol 255 does not)
             uint32_t end = c + f;
             if (end > kProbScale) end = kProbScale;
             for (uint32_t s = c; s < end; ++s) {
@@ -476,6 +491,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
                 entry(f, c, s, ftab[s], btab[s]);
             }
         }
+        big_freq = __ballot(big) != 0ull;
         __syncthreads();
     }
 
@@ -494,6 +510,26 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
     while (done < d.n) {
         const unsigned long long remain = d.n - done;
         const uint32_t want = remain < (unsigned long long)kDecTile ? (uint32_t)remain : (uint32_t)kDecTile;
+        if (want == (uint32_t)kDecTile && pos >= len && !big_freq) {
+            // stream exhausted (a desynchronised decoder runs dry long before its last symbol): no window, no shifts
+            uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+            __syncthreads();
+            dec_tile_dry(xs, (uint32_t)(uintptr_t)ftab + 4u * lane, (uint32_t)(uintptr_t)btab + 4u * lane,
+                         (uint32_t)(uintptr_t)rec + 2u * lane, (uint32_t)kDecBlocks);
+            x = xs;
+            __syncthreads();
+            const bool out_al = (((uintptr_t)(d.out + done)) & 3u) == 0u;
+            for (int i = lane * 4; i < kDecTile; i += 256) {
+                const uint2 r4 = *(const uint2*)&rec[i];
+                const uint32_t packed = (uint32_t)c2s[r4.x & (kProbScale - 1u)] | ((uint32_t)c2s[(r4.x >> 16) & (kProbScale - 1u)] << 8) |
+                                        ((uint32_t)c2s[r4.y & (kProbScale - 1u)] << 16) | ((uint32_t)c2s[(r4.y >> 16) & (kProbScale - 1u)] << 24);
+                if (out_al) *(uint32_t*)(d.out + done + i) = packed;
+                else for (int b = 0; b < 4; ++b) d.out[done + i + b] = (uint8_t)(packed >> (8 * b));
+            }
+            done += (unsigned long long)kDecTile;
+            ++n_fast;
+            continue;
+        }
         // Stage the stream window [wbase, wbase + kDecWinLds) into LDS (zero beyond len).  The base is chosen so
         // that its global address is dword aligned; when the whole window lies inside the stream all 33 dword
         // loads of a lane are issued back to back (one memory latency per tile instead of 33).
@@ -525,7 +561,14 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         // the owed renormalisation first (src/rans.rs:365-368); it needs at most a few window bytes
         // unless the state is 0, which the exact loop below handles byte by byte
         uint32_t got = 0u;
-        bool fast = (want == (uint32_t)kDecTile) && whole;
+        // Near the end of the stream the window is zero-padded and the fast tile runs speculatively: if it
+        // turns out to have consumed padding (it ran dry part-way) its result is dropped and the exact loop redoes
+        // the tile from the saved state.  A desynchronised decoder that eats a fraction of a bit per symbol spends
+        // hundreds of tiles inside the last window; they all stay on the fast path this way.
+        bool fast = (want == (uint32_t)kDecTile) && pos < len;
+        const uint32_t x_save = x;
+        const unsigned long long pos_save = pos;
+        const bool pending_save = pending;
         if (fast && pending) {
             uint32_t xs = x;
             unsigned long long ps = pos;
@@ -545,6 +588,12 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             pos = wbase + prel;
             pending = false;  // the fast path renormalises right after each update
             __syncthreads();
+            if (pos > len) {  // uniform: padding was consumed
+                x = x_save; pos = pos_save; pending = pending_save;
+                fast = false;
+            }
+        }
+        if (fast) {
             // symbols from the recorded states, 4 per lane; straight to global memory when the output is aligned
             const bool out_aligned = (((uintptr_t)(d.out + done)) & 3u) == 0u;
             for (int i = lane * 4; i < kDecTile; i += 256) {
