@@ -16,8 +16,8 @@ Register plan (all literal, all listed as clobbers by the including statement):
   v[192:224]  stream window, big-endian dwords (dword d in row d >> 6, lane d & 63)
   v225        record: pre-update state of the 64 symbols of the current block
   s[60:61]    {window copy : x} shift pair      s[62:63] 64-bit big-endian byte window      s[64:65] refill pair
-  s67 F'   s69 B'   s70 product   s71 shift   s72 valid window bits   s73 next window dword
-  s74 blocks left   s75 byte-swap selector   s76 row
+  s67 F'   s69 B'   s70 product   s71 shift   s72 valid window bits - 33   s73 next window dword
+  s74 blocks left   s75 byte-swap selector   s76 row   s77 shift of the odd symbol   s78 scratch
   s80..s100   renormalisation shift (0, 8 or 16) by count-leading-zeros of the state
 Operands: %[ta] %[tb] %[wa] (VGPR: per-lane LDS byte addresses), %[ra] (VGPR in/out: record address, 2 B per lane),
           %[xi] %[pi] %[nb] (SGPR in), %[xo] %[po] (SGPR out).
@@ -60,9 +60,11 @@ e("s_nop 1")
 e("v_readlane_b32 s62, v192, s73")
 e("s_add_u32 s73, s73, 1")
 e("s_lshl_b64 s[62:63], s[62:63], s71")
-e("s_sub_u32 s72, 64, s71")
+e("s_sub_u32 s72, 31, s71")   # 64 - shift - 33
 e("2:")
+# s72 holds (valid window bits - 33): the borrow of the one subtraction per symbol pair is the refill condition
 for lane in range(64):
+    sh = "s77" if lane & 1 else "s71"
     e("s_bfe_u32 s76, s61, 0x60006")
     e("s_set_gpr_idx_on s76, 0x1")
     e("v_readlane_b32 s67, v64, s61")
@@ -72,12 +74,12 @@ for lane in range(64):
     e("s_add_u32 s61, s70, s69")
     e("s_flbit_i32_b32 m0, s61")
     e("s_mov_b32 s60, s63")
-    e("s_movrels_b32 s71, s80")
-    e("s_lshl_b64 s[60:61], s[60:61], s71")
-    e("s_lshl_b64 s[62:63], s[62:63], s71")
-    e("s_sub_u32 s72, s72, s71")
+    e(f"s_movrels_b32 {sh}, s80")
+    e(f"s_lshl_b64 s[60:61], s[60:61], {sh}")
+    e(f"s_lshl_b64 s[62:63], s[62:63], {sh}")
     if lane & 1:
-        e("s_cmp_lt_u32 s72, 33")
+        e("s_add_u32 s78, s71, s77")
+        e("s_sub_u32 s72, s72, s78")            # SCC = borrow <=> fewer than 33 valid bits left
         e(f"s_cbranch_scc1 3{lane:02d}f")
         e(f"4{lane:02d}:")
 e("s_set_gpr_idx_off")
@@ -94,13 +96,15 @@ for lane in range(1, 64, 2):   # out-of-line refills
     e("s_mov_b32 s64, 0")
     e("v_readlane_b32 s65, v192, s73")
     e("s_add_u32 s73, s73, 1")
-    e("s_lshr_b64 s[64:65], s[64:65], s72")
+    e("s_add_u32 s78, s72, 33")                 # true number of valid bits (s72 has wrapped below zero)
+    e("s_lshr_b64 s[64:65], s[64:65], s78")
     e("s_or_b64 s[62:63], s[62:63], s[64:65]")
     e("s_add_u32 s72, s72, 32")
     e(f"s_branch 4{lane:02d}b")
 e("5:")
 e("s_lshl_b32 s70, s73, 2")
-e("s_lshr_b32 s71, s72, 3")
+e("s_add_u32 s71, s72, 33")
+e("s_lshr_b32 s71, s71, 3")
 e("s_sub_u32 %[po], s70, s71")
 e("s_mov_b32 %[xo], s61")
 e("s_waitcnt lgkmcnt(0)")
@@ -135,7 +139,7 @@ d("s_mov_b32 %[xo], s61")
 d("s_waitcnt lgkmcnt(0)")
 dry_clob = ["memory", "scc", "m0", "s61", "s67", "s69", "s70", "s74", "s76"] + [f"v{r}" for r in range(64, 192)] + [f"v{REC}"]
 
-clob = ["memory", "scc", "m0"] + [f"s{i}" for i in range(60, 77)] + [f"s{80 + c}" for c in range(21)]
+clob = ["memory", "scc", "m0"] + [f"s{i}" for i in range(60, 79)] + [f"s{80 + c}" for c in range(21)]
 clob += [f"v{r}" for r in range(64, REC + 1)]
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rans_decode_tile.inc")
 with open(out, "w") as f:
