@@ -162,6 +162,9 @@ def load_library() -> C.CDLL:
         "alice_codec_freq_table_from_histogram": (C.c_int, [_u32p, _u16p, _u16p]),
         "alice_codec_rans_encode": (vp, [_u8p, C.c_uint64, _u16p, _u16p, _u64p]),
         "alice_codec_rans_decode": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
+        "alice_codec_rdo_target_bpp": (C.c_double, [C.c_uint8]),
+        "alice_codec_subband_quant_strength": (C.c_uint8, [C.c_uint8]),
+        "alice_codec_rdo_compute_quantizer": (C.c_int, [C.c_double, _i32p, C.c_uint64, C.c_uint8, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "alice_codec_rans_encode_interleaved": (vp, [_u8p, C.c_uint64, _u16p, _u16p, _u64p]),
         "alice_codec_rans_decode_interleaved": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
         "alice_codec_rgb_to_ycocg_r": (C.c_int, [_u8p, C.c_uint64, _i16p, _i16p, _i16p, C.c_uint64]),
@@ -481,6 +484,52 @@ class Quantizer:
 
     def dequantize(self, q: int) -> int:
         return int(self.dequantize_buffer([q])[0])
+
+
+class SubBand3D(enum.IntEnum):  # reference src/lib.rs:115-158
+    LLL = 0
+    LLH = 1
+    LHL = 2
+    LHH = 3
+    HLL = 4
+    HLH = 5
+    HHL = 6
+    HHH = 7
+
+    def is_temporal_high(self) -> bool: return self in (SubBand3D.LLH, SubBand3D.LHH, SubBand3D.HLH, SubBand3D.HHH)
+
+    def is_dc(self) -> bool: return self is SubBand3D.LLL
+
+    def quant_strength(self) -> int: return int(load_library().alice_codec_subband_quant_strength(int(self)))
+
+
+class AnalyticalRDO:
+    """reference src/quant.rs:377-505: closed-form step per sub-band from the coefficient variance."""
+
+    def __init__(self, target_bpp: float):            # AnalyticalRDO::new
+        self._target_bpp, self._quality = float(target_bpp), 75
+
+    @classmethod
+    def with_quality(cls, quality: int) -> "AnalyticalRDO":
+        q = min(int(quality), 100)
+        r = cls(load_library().alice_codec_rdo_target_bpp(q))
+        r._quality = q
+        return r
+
+    def quality(self) -> int: return self._quality
+
+    def target_bpp(self) -> float: return self._target_bpp
+
+    def compute_quantizer(self, coeffs, subband: SubBand3D) -> Quantizer:
+        c = np.ascontiguousarray(coeffs, dtype=np.int32).reshape(-1)
+        st, dz = C.c_int32(), C.c_int32()
+        z = C.cast(C.c_char_p(b"\0\0\0\0"), _i32p)
+        _check(load_library().alice_codec_rdo_compute_quantizer(self._target_bpp, _p(c, _i32p) if c.size else z, c.size, int(subband),
+                                                                C.byref(st), C.byref(dz)))
+        return Quantizer.with_dead_zone(st.value, dz.value)
+
+    def compute_all_quantizers(self, subbands) -> list:
+        return [self.compute_quantizer(c, SubBand3D(i)) for i, c in enumerate(subbands)]
 
 
 class FastQuantizer:

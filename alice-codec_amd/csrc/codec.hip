@@ -1136,6 +1136,53 @@ int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t c
     return kOk;
 }
 
+// AnalyticalRDO (src/quant.rs:377-505) + SubBand3D::quant_strength (src/lib.rs:149-158)
+double alice_codec_rdo_target_bpp(uint8_t quality) {   // with_quality, :398-411
+    const double RCP_100 = 1.0 / 100.0;
+    const unsigned qq = quality > 100 ? 100u : quality;
+    const double q = (double)qq * RCP_100;
+    return fma(q * q, 23.9, 0.1);
+}
+uint8_t alice_codec_subband_quant_strength(uint8_t subband) {
+    switch (subband) { case 0: return 1; case 1: case 2: case 4: return 2; case 3: case 5: case 6: return 4; default: return 8; }
+}
+int alice_codec_rdo_compute_quantizer(double target_bpp, const int32_t* coeffs, uint64_t n, uint8_t subband, int32_t* step,
+                                      int32_t* dead_zone) {
+    clear_error();
+    if ((!coeffs && n) || !step || !dead_zone) return fail(kNullArgument, "null argument");
+    if (subband > 7) return fail(kInvalidDimensions, "unknown sub-band");
+    double variance = 1.0;                                           // estimate_variance of an empty slice, :415-417
+    if (n) {
+        hipStream_t st;
+        TRY(get_stream(&st));
+        DevBuf dx, dsum, dacc;
+        TRY(dx.alloc(n * sizeof(int32_t))); TRY(dsum.alloc(8)); TRY(dacc.alloc(8));
+        HIP_TRY(hipMemcpyAsync(dx.p, coeffs, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(dsum.p, 0, 8, st));
+        launch_sum_i32(dx.as<int32_t>(), n, dsum.as<unsigned long long>(), st);
+        long long sum = 0;
+        HIP_TRY(hipMemcpyAsync(&sum, dsum.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const double inv_n = 1.0 / (double)n;
+        const double mean = (double)sum * inv_n;                      // :421-424
+        launch_ordered_sqdev_sum(dx.as<int32_t>(), n, mean, dacc.as<double>(), st);
+        double acc = 0.0;
+        HIP_TRY(hipMemcpyAsync(&acc, dacc.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        variance = acc * inv_n;                                       // :426-433
+        if (!(variance > 1.0)) variance = 1.0;                        // f64::max(1.0)
+    }
+    const double lambda = (6.0 * M_LN2 * variance) / target_bpp;      // :440-443
+    const double r = round(sqrt(12.0 * lambda));                      // :448-451
+    int32_t base = r != r ? 0 : (r >= 2147483647.0 ? INT32_MAX : (r <= -2147483648.0 ? INT32_MIN : (int32_t)r));
+    if (base < 1) base = 1;
+    int32_t s = (int32_t)((uint32_t)base * (uint32_t)alice_codec_subband_quant_strength(subband));   // :461-462
+    if (s < 1) s = 1;
+    *step = s;
+    *dead_zone = (int32_t)((uint32_t)s + (uint32_t)(s / 2));          // :465
+    return kOk;
+}
+
 // InterleavedRansEncoder::{encode, finish} (src/rans.rs:393-456): four independent single-stream coders over the
 // sub-sequences i = j mod 4, behind a 32-byte header (4 stream lengths, 4 symbol counts, u32 LE).  On the GPU
 // that is four chains of the same encode kernel running side by side.

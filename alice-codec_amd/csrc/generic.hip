@@ -303,6 +303,52 @@ __global__ __launch_bounds__(256) void sq_diff_sum_kernel(const uint8_t* __restr
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
 }
 
+// ---- AnalyticalRDO::estimate_variance (src/quant.rs:414-435) ------------------------------------------------
+// The i64 sum is exact in any order.  The sum of squared deviations is an f64 fold in element order in the
+// reference, and f64 addition is not associative, so it is reproduced as such: all threads compute the terms
+// (x - mean)^2 of a 4096-element tile (each term rounds the same way wherever it is computed), then ONE lane adds
+// them in order.  8 cycles per element on a path that runs once per sub-band, not per pixel.
+__global__ __launch_bounds__(256) void sum_i32_kernel(const int32_t* __restrict__ x, unsigned long long n,
+                                                      unsigned long long* __restrict__ sum) {
+    long long acc = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
+        acc += (long long)x[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, (unsigned long long)acc);   // two's complement: wraps to the signed sum
+}
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void ordered_sqdev_sum_kernel(const int32_t* __restrict__ x, unsigned long long n, double mean,
+                                                                double* __restrict__ out) {
+    constexpr int T = 4096;
+    __shared__ double term[T];
+    double acc = 0.0;
+    for (unsigned long long base = 0; base < n; base += T) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += 256) {
+            const unsigned long long k = base + (unsigned long long)i;
+            double sq = 0.0;
+            if (k < n) { const double diff = (double)x[k] - mean; sq = diff * diff; }
+            term[i] = sq;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int m = (n - base) < (unsigned long long)T ? (int)(n - base) : T;
+            for (int i = 0; i < m; ++i) acc = acc + term[i];
+        }
+    }
+    if (threadIdx.x == 0) *out = acc;
+}
+#pragma clang fp contract(fast)
+void launch_sum_i32(const int32_t* d_x, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st) {
+    if (!n) return;
+    unsigned g = grid_for(n);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(sum_i32_kernel, dim3(g), dim3(256), 0, st, d_x, (unsigned long long)n, d_sum);
+}
+void launch_ordered_sqdev_sum(const int32_t* d_x, uint64_t n, double mean, double* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(ordered_sqdev_sum_kernel, dim3(1), dim3(256), 0, st, d_x, (unsigned long long)n, mean, d_out);
+}
+
 void launch_quantize(const int32_t* in, int32_t* out, uint64_t n, int32_t step, int32_t dead_zone, hipStream_t st) {
     if (!n) return;
     hipLaunchKernelGGL(quantize_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, out, (unsigned long long)n, step, dead_zone);

@@ -73,6 +73,9 @@ void launch_dequantize(const int32_t* in, int32_t* out, uint64_t n, int32_t step
 void launch_to_symbols(const int32_t* in, uint8_t* out, uint64_t n, hipStream_t st);
 void launch_from_symbols(const uint8_t* in, int32_t* out, uint64_t n, hipStream_t st);
 void launch_histogram(const uint8_t* sym, uint64_t n, uint32_t* hist /*zeroed*/, hipStream_t st);
+// AnalyticalRDO::estimate_variance pieces: exact i64 sum; f64 sum of (x - mean)^2 in element order
+void launch_sum_i32(const int32_t* d_x, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st);
+void launch_ordered_sqdev_sum(const int32_t* d_x, uint64_t n, double mean, double* d_out, hipStream_t st);
 void launch_sq_diff_sum(const uint8_t* a, const uint8_t* b, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st);
 // Each chunk's .alc buffer holds, behind `head` bytes, three cap-sized regions with a stream at the tail of
 // each; moves the streams, in place, to directly behind the 3138-byte header slot.

@@ -171,6 +171,13 @@ uint8_t *alice_codec_rans_encode(const uint8_t *symbols, uint64_t n, const uint1
 /* RansDecoder::new(bytes).decode_n(n, table) (src/rans.rs:330-381); cum_to_sym is rebuilt from the arrays */
 int alice_codec_rans_decode(const uint8_t *bytes, uint64_t len, const uint16_t cum_freq[256],
                             const uint16_t freq[256], uint64_t n, uint8_t *symbols);
+/* AnalyticalRDO (src/quant.rs:377-505): with_quality's target bits per pixel, and compute_quantizer for one
+ * sub-band (0 = LLL .. 7 = HHH, src/lib.rs:115-132) -> step and dead zone of the Quantizer it returns.  The f64
+ * sum of squared deviations is accumulated in element order, as the reference does, so the step is identical. */
+double alice_codec_rdo_target_bpp(uint8_t quality);
+uint8_t alice_codec_subband_quant_strength(uint8_t subband);     /* SubBand3D::quant_strength, src/lib.rs:149-158 */
+int alice_codec_rdo_compute_quantizer(double target_bpp, const int32_t *coeffs, uint64_t n, uint8_t subband,
+                                      int32_t *step, int32_t *dead_zone);
 /* InterleavedRansEncoder::new().encode(symbols, table).finish() (src/rans.rs:393-456): 32-byte header + four
  * independent streams over the sub-sequences i = j mod 4 (an opt-in format, not used by .alc v1).
  * Returns a buffer to free with alice_codec_data_free64, NULL on error. */

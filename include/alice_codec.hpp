@@ -159,6 +159,38 @@ struct Quantizer {  // src/quant.rs:57-153
     }
 };
 
+enum class SubBand3D : uint8_t { LLL = 0, LLH, LHL, LHH, HLL, HLH, HHL, HHH };  // src/lib.rs:115-132
+inline bool is_temporal_high(SubBand3D s) { return (static_cast<uint8_t>(s) & 1u) != 0; }          // LLH, LHH, HLH, HHH
+inline bool is_dc(SubBand3D s) { return s == SubBand3D::LLL; }
+inline uint8_t quant_strength(SubBand3D s) { return alice_codec_subband_quant_strength(static_cast<uint8_t>(s)); }
+
+class AnalyticalRDO {  // src/quant.rs:377-505
+public:
+    static AnalyticalRDO new_(double target_bpp) { return AnalyticalRDO(target_bpp, 75); }
+    static AnalyticalRDO with_quality(uint8_t quality) {
+        const uint8_t q = quality > 100 ? 100 : quality;
+        return AnalyticalRDO(alice_codec_rdo_target_bpp(q), q);
+    }
+    Quantizer compute_quantizer(const std::vector<int32_t>& coeffs, SubBand3D subband) const {
+        int32_t step = 1, dz = 1;
+        static const int32_t empty = 0;
+        detail::check(alice_codec_rdo_compute_quantizer(target_bpp_, coeffs.empty() ? &empty : coeffs.data(), coeffs.size(),
+                                                        static_cast<uint8_t>(subband), &step, &dz));
+        return Quantizer::with_dead_zone(step, dz);
+    }
+    std::array<Quantizer, 8> compute_all_quantizers(const std::array<std::vector<int32_t>, 8>& subbands) const {
+        std::array<Quantizer, 8> q{};
+        for (size_t i = 0; i < 8; ++i) q[i] = compute_quantizer(subbands[i], static_cast<SubBand3D>(i));
+        return q;
+    }
+    uint8_t quality() const { return quality_; }
+    double target_bpp() const { return target_bpp_; }
+private:
+    AnalyticalRDO(double bpp, uint8_t q) : target_bpp_(bpp), quality_(q) {}
+    double target_bpp_;
+    uint8_t quality_;
+};
+
 class FastQuantizer {  // src/quant.rs:171-359
 public:
     static FastQuantizer new_(int32_t step) { return FastQuantizer(alice_codec_fastquant_new(step)); }

@@ -126,6 +126,13 @@ def _bind(lib):
     lib.ao_decode_par3.argtypes = lib.ao_decode.argtypes
     lib.ao_encode_symbols.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint8, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    lib.ao_rdo_target_bpp.argtypes = [C.c_uint8]
+    lib.ao_rdo_target_bpp.restype = C.c_double
+    lib.ao_subband_quant_strength.argtypes = [C.c_int]
+    lib.ao_rdo_estimate_variance.argtypes = [_i32p, C.c_size_t]
+    lib.ao_rdo_estimate_variance.restype = C.c_double
+    lib.ao_rdo_compute_quantizer.argtypes = [C.c_double, _i32p, C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.ao_rdo_compute_quantizer.restype = None
     lib.ao_psnr.argtypes = [_u8p, _u8p, C.c_size_t]
     lib.ao_psnr.restype = C.c_double
     lib.ao_free.argtypes = [C.c_void_p]
@@ -376,6 +383,27 @@ def encode_symbols(rgb, width: int, height: int, frames: int, quality: int, wave
         return np.zeros((3, 0), np.uint8)
     raw = _take(out, 3 * n.value)
     return np.frombuffer(raw, np.uint8).reshape(3, n.value).copy()
+
+
+def rdo_target_bpp(quality: int) -> float:
+    return lib().ao_rdo_target_bpp(min(int(quality), 255))
+
+
+def subband_quant_strength(subband: int) -> int:
+    return lib().ao_subband_quant_strength(int(subband))
+
+
+def rdo_estimate_variance(coeffs) -> float:
+    c = np.ascontiguousarray(coeffs, dtype=np.int32).reshape(-1)
+    return lib().ao_rdo_estimate_variance(_ptr(c, _i32p), c.size)
+
+
+def rdo_compute_quantizer(target_bpp: float, coeffs, subband: int):
+    """AnalyticalRDO::compute_quantizer -> (step, dead_zone)."""
+    c = np.ascontiguousarray(coeffs, dtype=np.int32).reshape(-1)
+    st, dz = C.c_int32(), C.c_int32()
+    lib().ao_rdo_compute_quantizer(float(target_bpp), _ptr(c, _i32p), c.size, int(subband), C.byref(st), C.byref(dz))
+    return st.value, dz.value
 
 
 def psnr(a, b) -> float:

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * alice_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE)
  *
@@ -811,6 +812,53 @@ int ao_decode(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len
     *rgb = out;
     *rgb_len = n_pixels * 3;
     return AO_OK;
+}
+
+/* ---- AnalyticalRDO (src/quant.rs:377-505) and SubBand3D::quant_strength (src/lib.rs:149-158) ---------------- */
+double ao_rdo_target_bpp(uint8_t quality) { /* with_quality, :398-411 */
+    const double RCP_100 = 1.0 / 100.0;
+    unsigned qq = quality > 100 ? 100u : quality;
+    double q = (double)qq * RCP_100;
+    return fma(q * q, 23.9, 0.1); /* (q * q).mul_add(23.9, 0.1) */
+}
+int ao_subband_quant_strength(int subband) {
+    switch (subband) {
+    case 0: return 1;
+    case 1: case 2: case 4: return 2;
+    case 3: case 5: case 6: return 4;
+    default: return 8;
+    }
+}
+/* estimate_variance (:414-435): exact i64 sum, then a sequential f64 sum of squared deviations */
+double ao_rdo_estimate_variance(const int32_t *coeffs, size_t n) {
+    if (n == 0) return 1.0;
+    double nn = (double)n, inv_n = 1.0 / nn;
+    int64_t sum = 0;
+    for (size_t i = 0; i < n; ++i) sum += (int64_t)coeffs[i];
+    double mean = (double)sum * inv_n;
+    double acc = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        double diff = (double)coeffs[i] - mean;
+        double sq = diff * diff;
+        acc = acc + sq;
+    }
+    double variance = acc * inv_n;
+    return variance > 1.0 ? variance : 1.0; /* f64::max */
+}
+/* compute_quantizer (:455-470): step and dead zone of the Quantizer it returns */
+void ao_rdo_compute_quantizer(double target_bpp, const int32_t *coeffs, size_t n, int subband, int32_t *step,
+                              int32_t *dead_zone) {
+    double variance = ao_rdo_estimate_variance(coeffs, n);
+    double lambda = (6.0 * M_LN2 * variance) / target_bpp;     /* :440-443 */
+    double st = sqrt(12.0 * lambda);                          /* :448-451 */
+    double r = round(st);
+    int32_t base = (r >= 2147483647.0) ? INT32_MAX : (r <= -2147483648.0 ? INT32_MIN : (int32_t)r); /* `as i32` saturates */
+    if (r != r) base = 0;
+    if (base < 1) base = 1;
+    int32_t s = (int32_t)((uint32_t)base * (uint32_t)ao_subband_quant_strength(subband));
+    if (s < 1) s = 1;
+    *step = s;
+    *dead_zone = (int32_t)((uint32_t)s + (uint32_t)(s / 2));
 }
 
 /* ---- NOT the reference: the same encode/decode with the three channels on three threads --------------------

@@ -119,6 +119,12 @@ int ao_encode(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t heigh
               uint8_t quality, int wavelet, uint8_t **out, size_t *out_len);
 /* FrameDecoder::new().decode(EncodedChunk::from_bytes(..)); *rgb malloc'ed */
 int ao_decode(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len);
+/* AnalyticalRDO (src/quant.rs:377-505), SubBand3D::quant_strength (src/lib.rs:149-158) */
+double ao_rdo_target_bpp(uint8_t quality);
+int ao_subband_quant_strength(int subband);
+double ao_rdo_estimate_variance(const int32_t *coeffs, size_t n);
+void ao_rdo_compute_quantizer(double target_bpp, const int32_t *coeffs, size_t n, int subband, int32_t *step,
+                              int32_t *dead_zone);
 /* NOT the reference (it is single-threaded): the same two calls with Y, Co, Cg on three threads -- the hypothetical
  * "rayon::join" variant that bench.py times beside the faithful one.  Byte-identical results. */
 int ao_encode_par3(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t height, uint32_t frames,

@@ -310,6 +310,26 @@ def test_rans_streams(gpu_codec, oracle_mod):
         assert np.array_equal(gpu_codec.RansDecoder(data).decode_n(300, uni_g), oracle_mod.rans_decode(data, 300, uni_o))
 
 
+def test_analytical_rdo_matches_oracle(gpu_codec, oracle_mod):
+    """AnalyticalRDO::compute_quantizer (src/quant.rs:455-470): identical step and dead zone, because the f64 sum of
+    squared deviations is accumulated in element order on the GPU as well."""
+    rng = np.random.default_rng(99)
+    assert gpu_codec.AnalyticalRDO.with_quality(80).target_bpp() == oracle_mod.rdo_target_bpp(80)
+    assert [gpu_codec.SubBand3D(i).quant_strength() for i in range(8)] == [1, 2, 2, 4, 2, 4, 4, 8]
+    assert gpu_codec.SubBand3D.LHH.is_temporal_high() and not gpu_codec.SubBand3D.HHL.is_temporal_high() and gpu_codec.SubBand3D.LLL.is_dc()
+    for n in (0, 1, 2, 201, 4095, 4096, 4097, 100003):
+        for scale in (3, 4000, 2 ** 30):
+            c = rng.integers(-scale, scale + 1, n).astype(np.int32)
+            for q in (0, 37, 80, 100):
+                rdo = gpu_codec.AnalyticalRDO.with_quality(q)
+                for sb in (0, 3, 7):
+                    qz = rdo.compute_quantizer(c, gpu_codec.SubBand3D(sb))
+                    assert (qz.step, qz.dead_zone) == oracle_mod.rdo_compute_quantizer(oracle_mod.rdo_target_bpp(q), c, sb), (n, scale, q, sb)
+    alls = gpu_codec.AnalyticalRDO.with_quality(50).compute_all_quantizers([np.arange(-50, 51, dtype=np.int32)] * 8)
+    assert all(a.step > 0 for a in alls) and alls[0].step <= alls[7].step                     # src/quant.rs:1045-1070
+    assert gpu_codec.AnalyticalRDO(2.0).quality() == 75                                       # AnalyticalRDO::new, :388-393
+
+
 def test_interleaved_rans_streams(gpu_codec, oracle_mod):
     """InterleavedRansEncoder / InterleavedRansDecoder (src/rans.rs:393-519): four chains on the GPU; the
     reference's own round trips (src/rans.rs:745-780) plus every length residue."""

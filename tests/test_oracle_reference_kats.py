@@ -323,3 +323,25 @@ def test_three_thread_variant_is_byte_identical():
         a = o.encode(rgb, w, h, f, q, k)
         assert o.encode(rgb, w, h, f, q, k, three_threads=True) == a
         assert np.array_equal(o.decode(a), o.decode(a, three_threads=True))
+
+
+def test_analytical_rdo_reference_assertions():
+    """src/quant.rs:768-800, 1018-1070 and src/lib.rs:176-235 (the reference asserts orderings, not values)."""
+    import oracle as o
+    coeffs = np.arange(-100, 101, dtype=np.int32)
+    bpp50 = o.rdo_target_bpp(50)
+    lll = o.rdo_compute_quantizer(bpp50, coeffs, 0)
+    hhh = o.rdo_compute_quantizer(bpp50, coeffs, 7)
+    assert lll[0] > 0 and hhh[0] >= lll[0]
+    assert o.rdo_target_bpp(10) < o.rdo_target_bpp(90)
+    assert o.rdo_target_bpp(0) > 0.0 and o.rdo_target_bpp(100) > 20.0
+    assert o.rdo_target_bpp(100) == o.rdo_target_bpp(200)
+    data = np.arange(-50, 51, dtype=np.int32)
+    steps = [o.rdo_compute_quantizer(bpp50, data, i)[0] for i in range(8)]
+    assert all(s > 0 for s in steps) and steps[0] <= steps[7]
+    assert [o.subband_quant_strength(i) for i in range(8)] == [1, 2, 2, 4, 2, 4, 4, 8]
+    # doc example, src/quant.rs:371-374
+    assert o.rdo_compute_quantizer(o.rdo_target_bpp(80), np.array([10, -5, 3, 0, -1, 8, -2, 4], np.int32), 1)[0] >= 1
+    # hand check of the closed form: variance of -100..100 is 3350, lambda = 6 ln2 * 3350 / bpp, step = round(sqrt(12 lambda))
+    lam = 6.0 * np.log(2.0) * 3350.0 / bpp50
+    assert lll == (int(round(np.sqrt(12.0 * lam))), int(round(np.sqrt(12.0 * lam))) + int(round(np.sqrt(12.0 * lam))) // 2)
