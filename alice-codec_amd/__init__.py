@@ -162,6 +162,8 @@ def load_library() -> C.CDLL:
         "alice_codec_freq_table_from_histogram": (C.c_int, [_u32p, _u16p, _u16p]),
         "alice_codec_rans_encode": (vp, [_u8p, C.c_uint64, _u16p, _u16p, _u64p]),
         "alice_codec_rans_decode": (C.c_int, [_u8p, C.c_uint64, _u16p, _u16p, C.c_uint64, _u8p]),
+        "alice_codec_ssim": (C.c_double, [_u8p, C.c_uint64, _u8p, C.c_uint64, C.c_uint64, C.c_uint64]),
+        "alice_codec_ms_ssim": (C.c_double, [_u8p, C.c_uint64, _u8p, C.c_uint64, C.c_uint64, C.c_uint64]),
         "alice_codec_rdo_target_bpp": (C.c_double, [C.c_uint8]),
         "alice_codec_subband_quant_strength": (C.c_uint8, [C.c_uint8]),
         "alice_codec_rdo_compute_quantizer": (C.c_int, [C.c_double, _i32p, C.c_uint64, C.c_uint8, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -359,6 +361,25 @@ def psnr(a, b) -> float:
 # ---------------------------------------------------------------------------------------------
 # wavelets
 # ---------------------------------------------------------------------------------------------
+
+def _ssim(a, b, width: int, height: int, fn) -> float:
+    a = _as_u8(a); b = _as_u8(b)
+    z = C.cast(C.c_char_p(b""), _u8p)
+    v = fn(_p(a, _u8p) if a.size else z, a.size, _p(b, _u8p) if b.size else z, b.size, width, height)
+    if v == -1.0 and load_library().alice_codec_last_error() != 0:
+        _raise_last(1)
+    return v
+
+
+def ssim(a, b, width: int, height: int) -> float:
+    """reference src/ssim.rs:63-115"""
+    return _ssim(a, b, width, height, load_library().alice_codec_ssim)
+
+
+def ms_ssim(a, b, width: int, height: int) -> float:
+    """reference src/ssim.rs:125-176"""
+    return _ssim(a, b, width, height, load_library().alice_codec_ms_ssim)
+
 
 class Wavelet1D:
     """reference src/wavelet.rs:47-249 through the 6 drop-in FFI functions (src/ffi.rs:16-86)."""

@@ -1136,6 +1136,72 @@ int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t c
     return kOk;
 }
 
+// ssim / ms_ssim (src/ssim.rs:63-176).  Returns the value, or -1.0 with the thread's error set (the Result::Err cases).
+static int ssim_device(const uint8_t* d_a, const uint8_t* d_b, uint64_t w, uint64_t h, double* d_blocks, double* d_acc,
+                       hipStream_t st, double* out) {
+    const uint64_t bw = w / 8, bh = h / 8, nb = bw * bh;
+    if (nb == 0) { *out = 1.0; return kOk; }                              // block_count == 0, :111-113
+    launch_ssim_blocks(d_a, d_b, w, bw, nb, d_blocks, st);
+    launch_ordered_sum_f64(d_blocks, nb, d_acc, st);
+    double total = 0.0;
+    HIP_TRY(hipMemcpyAsync(&total, d_acc, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = total / (double)nb;
+    return kOk;
+}
+static int ssim_impl(const uint8_t* a, uint64_t a_len, const uint8_t* b, uint64_t b_len, uint64_t w, uint64_t h, bool multi, double* out) {
+    if (a_len != b_len) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(a_len) + ", got " + std::to_string(b_len));
+    unsigned __int128 wh = (unsigned __int128)w * h;
+    if (wh != a_len) return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string((uint64_t)wh) + ", got " + std::to_string(a_len));
+    if (a_len == 0) { *out = 1.0; return kOk; }
+    if (!a || !b) return fail(kNullArgument, "null argument");
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf da, db, da2, db2, dblk, dacc;
+    TRY(da.alloc(a_len)); TRY(db.alloc(a_len)); TRY(dblk.alloc(((w / 8) * (h / 8) + 1) * sizeof(double))); TRY(dacc.alloc(8));
+    HIP_TRY(hipMemcpyAsync(da.p, a, a_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(db.p, b, a_len, hipMemcpyHostToDevice, st));
+    if (!multi) return ssim_device(da.as<uint8_t>(), db.as<uint8_t>(), w, h, dblk.as<double>(), dacc.as<double>(), st, out);
+    TRY(da2.alloc(a_len / 4 + 1)); TRY(db2.alloc(a_len / 4 + 1));
+    const double weights[3] = {0.3333, 0.3333, 0.3334};
+    uint8_t *ca = da.as<uint8_t>(), *cb = db.as<uint8_t>(), *na = da2.as<uint8_t>(), *nb = db2.as<uint8_t>();
+    uint64_t cw = w, ch = h;
+    double result = 0.0;
+    for (int wi = 0; wi < 3; ++wi) {
+        const double weight = weights[wi];
+        double s = 0.0;
+        TRY(ssim_device(ca, cb, cw, ch, dblk.as<double>(), dacc.as<double>(), st, &s));
+        double l = log(s > 0.0 ? s : 0.0);                                   // s.max(0.0).ln().max(-10.0), :146
+        if (!(l > -10.0)) l = -10.0;
+        result += weight * l;
+        const uint64_t nw = cw / 2, nh = ch / 2;
+        if (nw < 8 || nh < 8) {
+            // the reference finds the current weight by value (first match), :153-163: the second scale maps to
+            // index 0 again and counts weights[1] once more
+            int pos = 0;
+            for (int k = 0; k < 3; ++k) if (fabs(weights[k] - weight) < 1e-10) { pos = k; break; }
+            for (int k = pos + 1; k < 3; ++k) result += weights[k] * l;
+            break;
+        }
+        launch_downsample2(ca, cw, ch, na, st);
+        launch_downsample2(cb, cw, ch, nb, st);
+        std::swap(ca, na); std::swap(cb, nb);
+        cw = nw; ch = nh;
+    }
+    *out = exp(result);
+    return kOk;
+}
+double alice_codec_ssim(const uint8_t* a, uint64_t a_len, const uint8_t* b, uint64_t b_len, uint64_t width, uint64_t height) {
+    clear_error();
+    double v = -1.0;
+    return ssim_impl(a, a_len, b, b_len, width, height, false, &v) == kOk ? v : -1.0;
+}
+double alice_codec_ms_ssim(const uint8_t* a, uint64_t a_len, const uint8_t* b, uint64_t b_len, uint64_t width, uint64_t height) {
+    clear_error();
+    double v = -1.0;
+    return ssim_impl(a, a_len, b, b_len, width, height, true, &v) == kOk ? v : -1.0;
+}
+
 // AnalyticalRDO (src/quant.rs:377-505) + SubBand3D::quant_strength (src/lib.rs:149-158)
 double alice_codec_rdo_target_bpp(uint8_t quality) {   // with_quality, :398-411
     const double RCP_100 = 1.0 / 100.0;

@@ -338,7 +338,74 @@ __global__ __launch_bounds__(256) void ordered_sqdev_sum_kernel(const int32_t* _
     }
     if (threadIdx.x == 0) *out = acc;
 }
+// ---- ssim (src/ssim.rs:18-115): one thread per 8x8 block.  All block sums are sums of multiples of 1/4096 below
+// 2^22, hence exact in f64 in any order; the scalar tail uses fma exactly where the reference uses mul_add; the
+// mean over the blocks is an f64 fold in raster order, done by one lane (ordered_sum_f64_kernel).
+__global__ __launch_bounds__(256) void ssim_blocks_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                          unsigned long long width, unsigned long long bw, unsigned long long nblocks,
+                                                          double* __restrict__ out) {
+    const unsigned long long blk = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nblocks) return;
+    const unsigned long long by = blk / bw, bx = blk % bw;
+    const uint8_t* pa = a + (by * 8) * width + bx * 8;
+    const uint8_t* pb = b + (by * 8) * width + bx * 8;
+    double sa = 0.0, sb = 0.0;
+    for (int dy = 0; dy < 8; ++dy)
+        for (int dx = 0; dx < 8; ++dx) { sa += (double)pa[dy * width + dx]; sb += (double)pb[dy * width + dx]; }
+    const double n = 64.0;
+    const double mu_a = sa / n, mu_b = sb / n;
+    double va = 0.0, vb = 0.0, vab = 0.0;
+    for (int dy = 0; dy < 8; ++dy)
+        for (int dx = 0; dx < 8; ++dx) {
+            const double da = (double)pa[dy * width + dx] - mu_a, db = (double)pb[dy * width + dx] - mu_b;
+            va += da * da; vb += db * db; vab += da * db;
+        }
+    const double denom = n - 1.0;
+    va /= denom; vb /= denom; vab /= denom;
+    const double C1 = 6.5025, C2 = 58.5225;
+    const double numerator = fma(2.0 * mu_a, mu_b, C1) * fma(2.0, vab, C2);
+    const double denominator = (fma(mu_a, mu_a, mu_b * mu_b) + C1) * (va + vb + C2);
+    out[blk] = numerator / denominator;
+}
+__global__ __launch_bounds__(256) void ordered_sum_f64_kernel(const double* __restrict__ v, unsigned long long n, double* __restrict__ out) {
+    constexpr int T = 4096;
+    __shared__ double term[T];
+    double acc = 0.0;
+    for (unsigned long long base = 0; base < n; base += T) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += 256) term[i] = (base + (unsigned long long)i < n) ? v[base + i] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int m = (n - base) < (unsigned long long)T ? (int)(n - base) : T;
+            for (int i = 0; i < m; ++i) acc = acc + term[i];
+        }
+    }
+    if (threadIdx.x == 0) *out = acc;
+}
+// downsample_2x (src/ssim.rs:181-200): truncating mean of each 2x2 cell
+__global__ __launch_bounds__(256) void downsample2_kernel(const uint8_t* __restrict__ in, unsigned long long width, unsigned long long nw,
+                                                          unsigned long long n_out, uint8_t* __restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const unsigned long long y = i / nw, x = i % nw;
+    const uint8_t* p = in + (2 * y) * width + 2 * x;
+    out[i] = (uint8_t)(((unsigned)p[0] + p[1] + p[width] + p[width + 1]) / 4u);
+}
 #pragma clang fp contract(fast)
+void launch_ssim_blocks(const uint8_t* d_a, const uint8_t* d_b, uint64_t width, uint64_t bw, uint64_t nblocks, double* d_out, hipStream_t st) {
+    if (!nblocks) return;
+    hipLaunchKernelGGL(ssim_blocks_kernel, dim3(grid_for(nblocks)), dim3(256), 0, st, d_a, d_b, (unsigned long long)width,
+                       (unsigned long long)bw, (unsigned long long)nblocks, d_out);
+}
+void launch_ordered_sum_f64(const double* d_v, uint64_t n, double* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(ordered_sum_f64_kernel, dim3(1), dim3(256), 0, st, d_v, (unsigned long long)n, d_out);
+}
+void launch_downsample2(const uint8_t* d_in, uint64_t width, uint64_t height, uint8_t* d_out, hipStream_t st) {
+    const uint64_t nw = width / 2, nh = height / 2;
+    if (!(nw * nh)) return;
+    hipLaunchKernelGGL(downsample2_kernel, dim3(grid_for(nw * nh)), dim3(256), 0, st, d_in, (unsigned long long)width,
+                       (unsigned long long)nw, (unsigned long long)(nw * nh), d_out);
+}
 void launch_sum_i32(const int32_t* d_x, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st) {
     if (!n) return;
     unsigned g = grid_for(n);

@@ -73,6 +73,10 @@ void launch_dequantize(const int32_t* in, int32_t* out, uint64_t n, int32_t step
 void launch_to_symbols(const int32_t* in, uint8_t* out, uint64_t n, hipStream_t st);
 void launch_from_symbols(const uint8_t* in, int32_t* out, uint64_t n, hipStream_t st);
 void launch_histogram(const uint8_t* sym, uint64_t n, uint32_t* hist /*zeroed*/, hipStream_t st);
+// ssim (src/ssim.rs): per-8x8-block values in raster order; f64 fold in element order; 2x2 truncating mean
+void launch_ssim_blocks(const uint8_t* d_a, const uint8_t* d_b, uint64_t width, uint64_t bw, uint64_t nblocks, double* d_out, hipStream_t st);
+void launch_ordered_sum_f64(const double* d_v, uint64_t n, double* d_out, hipStream_t st);
+void launch_downsample2(const uint8_t* d_in, uint64_t width, uint64_t height, uint8_t* d_out, hipStream_t st);
 // AnalyticalRDO::estimate_variance pieces: exact i64 sum; f64 sum of (x - mean)^2 in element order
 void launch_sum_i32(const int32_t* d_x, uint64_t n, unsigned long long* d_sum /*zeroed*/, hipStream_t st);
 void launch_ordered_sqdev_sum(const int32_t* d_x, uint64_t n, double mean, double* d_out, hipStream_t st);

@@ -171,6 +171,11 @@ uint8_t *alice_codec_rans_encode(const uint8_t *symbols, uint64_t n, const uint1
 /* RansDecoder::new(bytes).decode_n(n, table) (src/rans.rs:330-381); cum_to_sym is rebuilt from the arrays */
 int alice_codec_rans_decode(const uint8_t *bytes, uint64_t len, const uint16_t cum_freq[256],
                             const uint16_t freq[256], uint64_t n, uint8_t *symbols);
+/* ssim / ms_ssim (src/ssim.rs:63-176): mean SSIM over 8x8 blocks of two single-plane images, and the 3-scale
+ * variant.  Bit-identical f64 results (block sums are exact, the mean over blocks is folded in raster order).
+ * Returns -1.0 on the reference's Err cases (length mismatch), with alice_codec_last_error() set. */
+double alice_codec_ssim(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len, uint64_t width, uint64_t height);
+double alice_codec_ms_ssim(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len, uint64_t width, uint64_t height);
 /* AnalyticalRDO (src/quant.rs:377-505): with_quality's target bits per pixel, and compute_quantizer for one
  * sub-band (0 = LLL .. 7 = HHH, src/lib.rs:115-132) -> step and dead zone of the Quantizer it returns.  The f64
  * sum of squared deviations is accumulated in element order, as the reference does, so the step is identical. */

@@ -308,4 +308,17 @@ inline double psnr(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b)
     return alice_codec_psnr(a.empty() ? &empty : a.data(), b.empty() ? &empty : b.data(), static_cast<uint32_t>(a.size()));
 }
 
+inline double ssim(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b, size_t width, size_t height) {  // src/ssim.rs:63
+    static const uint8_t empty = 0;
+    const double v = alice_codec_ssim(a.empty() ? &empty : a.data(), a.size(), b.empty() ? &empty : b.data(), b.size(), width, height);
+    if (v == -1.0 && alice_codec_last_error() != 0) detail::raise();
+    return v;
+}
+inline double ms_ssim(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b, size_t width, size_t height) {  // src/ssim.rs:125
+    static const uint8_t empty = 0;
+    const double v = alice_codec_ms_ssim(a.empty() ? &empty : a.data(), a.size(), b.empty() ? &empty : b.data(), b.size(), width, height);
+    if (v == -1.0 && alice_codec_last_error() != 0) detail::raise();
+    return v;
+}
+
 }  // namespace alice_codec

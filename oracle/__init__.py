@@ -126,6 +126,8 @@ def _bind(lib):
     lib.ao_decode_par3.argtypes = lib.ao_decode.argtypes
     lib.ao_encode_symbols.argtypes = [_u8p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint8, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    lib.ao_ssim.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
+    lib.ao_ms_ssim.argtypes = lib.ao_ssim.argtypes
     lib.ao_rdo_target_bpp.argtypes = [C.c_uint8]
     lib.ao_rdo_target_bpp.restype = C.c_double
     lib.ao_subband_quant_strength.argtypes = [C.c_int]
@@ -383,6 +385,13 @@ def encode_symbols(rgb, width: int, height: int, frames: int, quality: int, wave
         return np.zeros((3, 0), np.uint8)
     raw = _take(out, 3 * n.value)
     return np.frombuffer(raw, np.uint8).reshape(3, n.value).copy()
+
+
+def ssim(a, b, width: int, height: int, multi_scale: bool = False) -> float:
+    a = _u8(a).reshape(-1); b = _u8(b).reshape(-1)
+    out = C.c_double()
+    _check((lib().ao_ms_ssim if multi_scale else lib().ao_ssim)(_ptr(a, _u8p), a.size, _ptr(b, _u8p), b.size, width, height, C.byref(out)))
+    return out.value
 
 
 def rdo_target_bpp(quality: int) -> float:

@@ -814,6 +814,98 @@ int ao_decode(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len
     return AO_OK;
 }
 
+/* ---- SSIM / MS-SSIM (src/ssim.rs:12-200) ---------------------------------------------------------------- */
+static double ssim_raw(const double *a, const double *b, size_t len) { /* :18-49 */
+    double n = (double)len;
+    if (n < 1.0) return 1.0;
+    double sa = 0.0, sb = 0.0;
+    for (size_t i = 0; i < len; ++i) sa += a[i];
+    for (size_t i = 0; i < len; ++i) sb += b[i];
+    double mu_a = sa / n, mu_b = sb / n;
+    double va = 0.0, vb = 0.0, vab = 0.0;
+    for (size_t i = 0; i < len; ++i) {
+        double da = a[i] - mu_a, db = b[i] - mu_b;
+        va += da * da; vb += db * db; vab += da * db;
+    }
+    double denom = (n - 1.0) > 1.0 ? (n - 1.0) : 1.0;
+    va /= denom; vb /= denom; vab /= denom;
+    const double C1 = 6.5025, C2 = 58.5225;
+    double numerator = fma(2.0 * mu_a, mu_b, C1) * fma(2.0, vab, C2);
+    double denominator = (fma(mu_a, mu_a, mu_b * mu_b) + C1) * (va + vb + C2);
+    return numerator / denominator;
+}
+int ao_ssim(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, size_t width, size_t height, double *out) {
+    if (a_len != b_len) return AO_ERR_INVALID_BUFFER_SIZE;     /* :64-69 */
+    if (a_len != width * height) return AO_ERR_INVALID_BUFFER_SIZE; /* :70-75 */
+    if (a_len == 0) { *out = 1.0; return AO_OK; }
+    double total = 0.0;
+    uint64_t count = 0;
+    double ba[64], bb[64];
+    size_t bh = height / 8, bw = width / 8;
+    for (size_t by = 0; by < bh; ++by)
+        for (size_t bx = 0; bx < bw; ++bx) {
+            size_t k = 0;
+            for (size_t dy = 0; dy < 8; ++dy)
+                for (size_t dx = 0; dx < 8; ++dx) {
+                    size_t idx = (by * 8 + dy) * width + bx * 8 + dx;
+                    ba[k] = (double)a[idx]; bb[k] = (double)b[idx]; ++k;
+                }
+            total += ssim_raw(ba, bb, 64);
+            count += 1;
+        }
+    *out = count == 0 ? 1.0 : total / (double)count;
+    return AO_OK;
+}
+static uint8_t *downsample_2x(const uint8_t *buf, size_t width, size_t height) { /* :181-200 */
+    size_t nw = width / 2, nh = height / 2;
+    uint8_t *out = (uint8_t *)malloc(nw * nh ? nw * nh : 1);
+    if (!out) return NULL;
+    for (size_t y = 0; y < nh; ++y)
+        for (size_t x = 0; x < nw; ++x) {
+            size_t sy = y * 2, sx = x * 2;
+            unsigned avg = ((unsigned)buf[sy * width + sx] + buf[sy * width + sx + 1] + buf[(sy + 1) * width + sx] +
+                            buf[(sy + 1) * width + sx + 1]) / 4;
+            out[y * nw + x] = (uint8_t)avg;
+        }
+    return out;
+}
+int ao_ms_ssim(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, size_t width, size_t height, double *out) {
+    if (a_len != b_len) return AO_ERR_INVALID_BUFFER_SIZE;
+    if (a_len != width * height) return AO_ERR_INVALID_BUFFER_SIZE;
+    if (a_len == 0) { *out = 1.0; return AO_OK; }
+    const double weights[3] = {0.3333, 0.3333, 0.3334};
+    uint8_t *ca = (uint8_t *)malloc(a_len), *cb = (uint8_t *)malloc(a_len);
+    if (!ca || !cb) { free(ca); free(cb); return AO_ERR_NOMEM; }
+    memcpy(ca, a, a_len); memcpy(cb, b, a_len);
+    size_t cw = width, ch = height;
+    double result = 0.0;
+    for (int wi = 0; wi < 3; ++wi) {
+        double weight = weights[wi], s = 0.0;
+        int rc = ao_ssim(ca, cw * ch, cb, cw * ch, cw, ch, &s);
+        if (rc) { free(ca); free(cb); return rc; }
+        double l = log(s > 0.0 ? s : 0.0);              /* s.max(0.0).ln().max(-10.0) */
+        if (!(l > -10.0)) l = -10.0;
+        result += weight * l;
+        size_t nw = cw / 2, nh = ch / 2;
+        if (nw < 8 || nh < 8) {
+            /* the reference looks the current weight up BY VALUE (first match), :153-163: on the second scale that is
+             * index 0 again, so weights[1] is counted once more */
+            int pos = 0;
+            for (int k = 0; k < 3; ++k) if (fabs(weights[k] - weight) < 1e-10) { pos = k; break; }
+            for (int k = pos + 1; k < 3; ++k) result += weights[k] * l;
+            break;
+        }
+        uint8_t *na = downsample_2x(ca, cw, ch), *nb = downsample_2x(cb, cw, ch);
+        free(ca); free(cb);
+        ca = na; cb = nb;
+        if (!ca || !cb) { free(ca); free(cb); return AO_ERR_NOMEM; }
+        cw = nw; ch = nh;
+    }
+    free(ca); free(cb);
+    *out = exp(result);
+    return AO_OK;
+}
+
 /* ---- AnalyticalRDO (src/quant.rs:377-505) and SubBand3D::quant_strength (src/lib.rs:149-158) ---------------- */
 double ao_rdo_target_bpp(uint8_t quality) { /* with_quality, :398-411 */
     const double RCP_100 = 1.0 / 100.0;

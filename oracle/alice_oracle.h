@@ -119,6 +119,9 @@ int ao_encode(const uint8_t *rgb, size_t rgb_len, uint32_t width, uint32_t heigh
               uint8_t quality, int wavelet, uint8_t **out, size_t *out_len);
 /* FrameDecoder::new().decode(EncodedChunk::from_bytes(..)); *rgb malloc'ed */
 int ao_decode(const uint8_t *alc, size_t alc_len, uint8_t **rgb, size_t *rgb_len);
+/* ssim / ms_ssim (src/ssim.rs:63-176): mean SSIM over 8x8 blocks; 3-scale variant */
+int ao_ssim(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, size_t width, size_t height, double *out);
+int ao_ms_ssim(const uint8_t *a, size_t a_len, const uint8_t *b, size_t b_len, size_t width, size_t height, double *out);
 /* AnalyticalRDO (src/quant.rs:377-505), SubBand3D::quant_strength (src/lib.rs:149-158) */
 double ao_rdo_target_bpp(uint8_t quality);
 int ao_subband_quant_strength(int subband);

@@ -310,6 +310,23 @@ def test_rans_streams(gpu_codec, oracle_mod):
         assert np.array_equal(gpu_codec.RansDecoder(data).decode_n(300, uni_g), oracle_mod.rans_decode(data, 300, uni_o))
 
 
+def test_ssim_matches_oracle_bit_for_bit(gpu_codec, oracle_mod):
+    """ssim / ms_ssim (src/ssim.rs:63-176): identical f64 values (exact block sums, ordered mean over blocks)."""
+    rng = np.random.default_rng(123)
+    for (w, h) in [(64, 64), (8, 8), (7, 9), (16, 8), (250, 131), (1920, 1080), (33, 64)]:
+        a = rng.integers(0, 256, w * h, dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.integers(-12, 13, w * h), 0, 255).astype(np.uint8)
+        assert gpu_codec.ssim(a, b, w, h) == oracle_mod.ssim(a, b, w, h), (w, h)
+        assert gpu_codec.ms_ssim(a, b, w, h) == oracle_mod.ssim(a, b, w, h, multi_scale=True), (w, h)
+        assert gpu_codec.ssim(a, a, w, h) == oracle_mod.ssim(a, a, w, h)
+    e = np.zeros(0, np.uint8)
+    assert gpu_codec.ssim(e, e, 0, 0) == 1.0 and gpu_codec.ms_ssim(e, e, 0, 0) == 1.0
+    with pytest.raises(gpu_codec.CodecError):
+        gpu_codec.ssim(np.zeros(100, np.uint8), np.zeros(200, np.uint8), 10, 10)
+    with pytest.raises(gpu_codec.CodecError):
+        gpu_codec.ssim(np.zeros(100, np.uint8), np.zeros(100, np.uint8), 8, 8)
+
+
 def test_analytical_rdo_matches_oracle(gpu_codec, oracle_mod):
     """AnalyticalRDO::compute_quantizer (src/quant.rs:455-470): identical step and dead zone, because the f64 sum of
     squared deviations is accumulated in element order on the GPU as well."""

@@ -345,3 +345,26 @@ def test_analytical_rdo_reference_assertions():
     # hand check of the closed form: variance of -100..100 is 3350, lambda = 6 ln2 * 3350 / bpp, step = round(sqrt(12 lambda))
     lam = 6.0 * np.log(2.0) * 3350.0 / bpp50
     assert lll == (int(round(np.sqrt(12.0 * lam))), int(round(np.sqrt(12.0 * lam))) + int(round(np.sqrt(12.0 * lam))) // 2)
+
+
+def test_ssim_reference_assertions():
+    """src/ssim.rs:211-320"""
+    import oracle as o
+    buf = np.full(64 * 64, 128, np.uint8)
+    assert abs(o.ssim(buf, buf, 64, 64) - 1.0) < 1e-6
+    d = o.ssim(np.full(4096, 100, np.uint8), np.full(4096, 200, np.uint8), 64, 64)
+    assert 0.0 < d < 1.0
+    b = buf.copy(); b[0] = 129
+    assert o.ssim(buf, b, 64, 64) > 0.99
+    x = (np.arange(4096) % 256).astype(np.uint8); y = ((np.arange(4096) + 10) % 256).astype(np.uint8)
+    assert abs(o.ssim(x, y, 64, 64) - o.ssim(y, x, 64, 64)) < 1e-10
+    with pytest.raises(o.OracleError):
+        o.ssim(np.zeros(100, np.uint8), np.zeros(200, np.uint8), 10, 10)
+    with pytest.raises(o.OracleError):
+        o.ssim(np.zeros(100, np.uint8), np.zeros(100, np.uint8), 8, 8)
+    assert o.ssim(np.zeros(0, np.uint8), np.zeros(0, np.uint8), 0, 0) == 1.0
+    assert abs(o.ssim(buf, buf, 64, 64, multi_scale=True) - 1.0) < 0.01
+    assert o.ssim(np.full(4096, 50, np.uint8), np.full(4096, 200, np.uint8), 64, 64, multi_scale=True) < 1.0
+    assert o.ssim(np.zeros(0, np.uint8), np.zeros(0, np.uint8), 0, 0, multi_scale=True) == 1.0
+    r = o.ssim(((np.arange(4096) * 7) % 256).astype(np.uint8), (255 - (np.arange(4096) * 7) % 256).astype(np.uint8), 64, 64)
+    assert -1.0 <= r <= 1.0
