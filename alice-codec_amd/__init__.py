@@ -130,6 +130,8 @@ def load_library() -> C.CDLL:
         "alice_codec_chunk_to_bytes64": (vp, [vp, _u64p]),
         "alice_codec_chunk_from_bytes64": (vp, [_u8p, C.c_uint64]),
         "alice_codec_data_free64": (None, [vp, C.c_uint64]),
+        "alice_codec_encode_many": (C.c_int, [vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "alice_codec_decode_many": (C.c_int, [C.POINTER(vp), C.c_uint32, _u8p, C.c_uint64]),
         "alice_codec_batch_create": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8]),
         "alice_codec_batch_destroy": (None, [vp]),
         "alice_codec_batch_encode": (C.c_int, [vp, vp, vp]),
@@ -332,6 +334,34 @@ class FrameEncoder:
         if not h:
             _raise_last()
         return EncodedChunk(h)
+
+
+def encode_many(encoder: "FrameEncoder", rgb_chunks, width: int, height: int, frames: int) -> list:
+    """n equal-shaped chunks (array of shape [n, frames*height*width*3] or a flat buffer) in one call: all their
+    entropy chains run side by side.  Returns n EncodedChunk, identical to n FrameEncoder.encode calls."""
+    lib = load_library()
+    r = _as_u8(rgb_chunks)
+    per = width * height * frames * 3
+    if per == 0 or r.size % per:
+        raise CodecError(1, "buffer is not a whole number of chunks")
+    n = r.size // per
+    handles = (C.c_void_p * n)()
+    _check(lib.alice_codec_encode_many(encoder._h, _p(r, _u8p), r.size, width, height, frames, n, handles))
+    return [EncodedChunk(h) for h in handles]
+
+
+def decode_many(chunks) -> np.ndarray:
+    """n equal-shaped chunks -> uint8 array [n, frames*height*width*3]"""
+    lib = load_library()
+    n = len(chunks)
+    if n == 0:
+        return np.zeros((0, 0), np.uint8)
+    per = chunks[0].width * chunks[0].height * chunks[0].frames * 3
+    out = np.zeros((n, per), np.uint8)
+    handles = (C.c_void_p * n)(*[c._h for c in chunks])
+    z = C.cast(C.c_char_p(b""), _u8p)
+    _check(lib.alice_codec_decode_many(handles, n, _p(out, _u8p) if out.size else z, out.size))
+    return out
 
 
 class FrameDecoder:

@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-from . import DEFAULT_CHUNK_SIZE, CodecError, EncodedChunk, FrameDecoder, FrameEncoder, WaveletType
+from . import DEFAULT_CHUNK_SIZE, CodecError, EncodedChunk, FrameDecoder, FrameEncoder, WaveletType, encode_many
 
 WAVELETS = {"cdf53": WaveletType.Cdf53, "cdf97": WaveletType.Cdf97, "haar": WaveletType.Haar}
 WAVELET_NAMES = {WaveletType.Cdf53: "CDF 5/3", WaveletType.Cdf97: "CDF 9/7", WaveletType.Haar: "Haar"}
@@ -44,15 +44,21 @@ def cmd_encode_chunks(a) -> None:
         raise ValueError("input size is not a whole number of frames")
     n_frames = rgb.size // frame_bytes
     enc = FrameEncoder.with_wavelet(a.quality, wt)
+    starts = list(range(0, n_frames, a.chunk))
     k = 0
-    for start in range(0, n_frames, a.chunk):
-        f = min(a.chunk, n_frames - start)
-        part = np.ascontiguousarray(rgb[start * frame_bytes:(start + f) * frame_bytes])
-        data = enc.encode(part, a.width, a.height, f).to_bytes()
-        with open(f"{a.output}.{k:05d}.alc", "wb") as out:
-            out.write(data)
-        print(f"chunk {k}: frames {start}..{start + f - 1} -> {len(data)} bytes", file=sys.stderr)
-        k += 1
+    i = 0
+    while i < len(starts):
+        # whole chunks go through one call per group (their entropy chains run side by side); a short tail chunk alone
+        group = [s0 for s0 in starts[i:i + a.in_flight] if n_frames - s0 >= a.chunk] or [starts[i]]
+        f = min(a.chunk, n_frames - group[0])
+        part = np.ascontiguousarray(rgb[group[0] * frame_bytes:(group[-1] + f) * frame_bytes])
+        for start, chunk in zip(group, encode_many(enc, part, a.width, a.height, f)):
+            data = chunk.to_bytes()
+            with open(f"{a.output}.{k:05d}.alc", "wb") as out:
+                out.write(data)
+            print(f"chunk {k}: frames {start}..{start + f - 1} -> {len(data)} bytes", file=sys.stderr)
+            k += 1
+        i += len(group)
 
 
 def cmd_decode(a) -> None:
@@ -93,6 +99,7 @@ def main(argv=None) -> int:
             e.add_argument("-f", "--frames", type=int, default=1)
         else:
             e.add_argument("-c", "--chunk", type=int, default=DEFAULT_CHUNK_SIZE)
+            e.add_argument("--in-flight", type=int, default=16, help="chunks encoded per call (GPU memory: about 2.4x the raw size of a chunk each)")
         e.add_argument("-q", "--quality", type=int, default=90)
         e.add_argument("-w", "--wavelet", default="cdf53")
     d = sub.add_parser("decode")

@@ -1395,6 +1395,99 @@ int alice_codec_ycocg_r_to_rgb(const int16_t* y, const int16_t* co, const int16_
     return kOk;
 }
 
+// ---- many chunks from host memory in one call: the chunk driver's fast path (the chains of all chunks run side
+// by side; a single chunk is bound by its three serial chains) ----
+
+int alice_codec_encode_many(const FrameEncoder* encoder, const uint8_t* rgb, uint64_t rgb_len, uint32_t width, uint32_t height,
+                            uint32_t frames, uint32_t n_chunks, EncodedChunk** out_chunks) {
+    clear_error();
+    if (!encoder || !out_chunks || (!rgb && rgb_len)) return fail(kNullArgument, "null argument");
+    for (uint32_t i = 0; i < n_chunks; ++i) out_chunks[i] = nullptr;
+    if (n_chunks == 0) return kOk;
+    uint64_t n_pixels = 0;
+    TRY(checked_pixel_count(width, height, frames, &n_pixels));
+    if (n_pixels == 0 || width == 0 || height == 0) return fail(kInvalidDimensions, "invalid dimensions");
+    if (n_pixels > UINT64_MAX / 3 / n_chunks) return fail(kDimensionOverflow, "dimensions overflow usize");
+    if (rgb_len != n_pixels * 3 * n_chunks)
+        return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n_pixels * 3 * n_chunks) + ", got " + std::to_string(rgb_len));
+    const ChunkDims d = make_dims(width, height, frames);
+    if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count does not fit the header's u32 num_symbols");
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf d_rgb;
+    TRY(d_rgb.alloc(rgb_len));
+    HIP_TRY(hipMemcpyAsync(d_rgb.p, rgb, rgb_len, hipMemcpyHostToDevice, st));
+    EncodeWork w;
+    std::vector<RansResult> res;
+    TRY(encode_work_alloc(w, d, (int)n_chunks));
+    for (int attempt = 0;; ++attempt) {
+        TRY(encode_launch(d_rgb.as<uint8_t>(), w, encoder->quality, encoder->wavelet, st, nullptr, attempt ? worst_cap(d) : 0));
+        const int rc = encode_collect(w, st, res);
+        if (rc == kOk) break;
+        if (rc != -1 || attempt > 0) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
+    }
+    std::vector<uint8_t> alc;
+    for (uint32_t i = 0; i < n_chunks; ++i) {
+        const uint64_t payload = res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
+        alc.resize((size_t)kAlcHeaderBytes + payload);
+        HIP_TRY(hipMemcpyAsync(alc.data(), w.alc.as<uint8_t>() + (size_t)i * w.alc_stride, alc.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        EncodedChunk* c = new (std::nothrow) EncodedChunk();
+        uint64_t tot = 0;
+        if (!c || parse_alc_header(alc.data(), alc.size(), *c, &tot) != kOk || tot != payload) {
+            delete c;
+            for (uint32_t k = 0; k < i; ++k) { delete out_chunks[k]; out_chunks[k] = nullptr; }
+            return fail(kInternal, "device header/payload length mismatch");
+        }
+        c->data.assign(alc.begin() + kAlcHeaderBytes, alc.end());
+        out_chunks[i] = c;
+    }
+    return kOk;
+}
+
+int alice_codec_decode_many(const EncodedChunk* const* chunks, uint32_t n_chunks, uint8_t* rgb_out, uint64_t rgb_out_len) {
+    clear_error();
+    if (!chunks || (!rgb_out && rgb_out_len)) return fail(kNullArgument, "null argument");
+    if (n_chunks == 0) return kOk;
+    for (uint32_t i = 0; i < n_chunks; ++i) {
+        if (!chunks[i]) return fail(kNullArgument, "null chunk");
+        if (chunks[i]->width != chunks[0]->width || chunks[i]->height != chunks[0]->height || chunks[i]->frames != chunks[0]->frames)
+            return fail(kInvalidDimensions, "chunks of one call must have the same shape");
+    }
+    ChunkDims d;
+    std::vector<EncodedChunk> hdrs(n_chunks);
+    uint64_t total_payload = 0;
+    for (uint32_t i = 0; i < n_chunks; ++i) {
+        TRY(validate_for_decode(*chunks[i], &d, chunks[i]->data.size()));
+        hdrs[i].width = chunks[i]->width; hdrs[i].height = chunks[i]->height; hdrs[i].frames = chunks[i]->frames; hdrs[i].wavelet = chunks[i]->wavelet;
+        for (int k = 0; k < 3; ++k) hdrs[i].ch[k] = chunks[i]->ch[k];
+        total_payload += round_up(chunks[i]->data.size() + 16, 256);
+    }
+    if (d.n_pixels == 0) return rgb_out_len == 0 ? kOk : fail(kInvalidBufferSize, "output buffer size mismatch");
+    if (rgb_out_len != d.n_pixels * 3 * n_chunks)
+        return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(d.n_pixels * 3 * n_chunks) + ", got " + std::to_string(rgb_out_len));
+    hipStream_t st;
+    TRY(get_stream(&st));
+    DevBuf d_payload, d_rgb;
+    TRY(d_payload.alloc(total_payload + 256));
+    TRY(d_rgb.alloc(rgb_out_len));
+    std::vector<const uint8_t*> pay(n_chunks);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n_chunks; ++i) {
+        pay[i] = d_payload.as<uint8_t>() + off;
+        if (!chunks[i]->data.empty())
+            HIP_TRY(hipMemcpyAsync(d_payload.as<uint8_t>() + off, chunks[i]->data.data(), chunks[i]->data.size(), hipMemcpyHostToDevice, st));
+        off += round_up(chunks[i]->data.size() + 16, 256);
+    }
+    DecodeWork w;
+    TRY(decode_work_alloc(w, d, (int)n_chunks));
+    TRY(decode_launch(hdrs, pay, w, d_rgb.as<uint8_t>(), st, nullptr));
+    TRY(decode_collect(w, st));
+    HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb.p, rgb_out_len, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+
 // ---- PART 3: device-resident stage calls (building blocks of the row-slab sharded path) ----
 // Every pointer named d_* is a device pointer; launches go on `hip_stream` and the call returns after the
 // stream has drained (the rANS calls need their result on the host anyway).

@@ -105,6 +105,13 @@ uint8_t *alice_codec_chunk_to_bytes64(const EncodedChunk *chunk, uint64_t *out_l
 EncodedChunk *alice_codec_chunk_from_bytes64(const uint8_t *data, uint64_t len);
 void alice_codec_data_free64(uint8_t *ptr, uint64_t len);
 
+/* ---- many equal-shaped chunks from host memory in one call (what a 64-frame chunk driver wants: the serial
+ * entropy chains of all chunks run side by side).  rgb = n_chunks chunks back to back; out_chunks[n_chunks] receives
+ * handles to free with alice_codec_chunk_destroy.  Same results as n_chunks calls of alice_codec_encode64. ---- */
+int alice_codec_encode_many(const FrameEncoder *encoder, const uint8_t *rgb, uint64_t rgb_len, uint32_t width,
+                            uint32_t height, uint32_t frames, uint32_t n_chunks, EncodedChunk **out_chunks);
+int alice_codec_decode_many(const EncodedChunk *const *chunks, uint32_t n_chunks, uint8_t *rgb_out, uint64_t rgb_out_len);
+
 /* ---- device-resident batches: n_chunks equal-shaped chunks, inputs and outputs in HBM ---- */
 typedef struct AliceBatch AliceBatch;
 AliceBatch *alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t frames, uint32_t n_chunks,

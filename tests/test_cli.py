@@ -47,3 +47,28 @@ def test_cli_encode_decode_files(gpu_codec, oracle_mod, tmp_path):
     fb = w * h * 3
     assert (tmp_path / "c.00000.alc").read_bytes() == oracle_mod.encode(rgb[:64 * fb], w, h, 64, 80, 1)
     assert (tmp_path / "c.00001.alc").read_bytes() == oracle_mod.encode(rgb[64 * fb:], w, h, 6, 80, 1)
+
+
+@pytest.mark.gpu
+def test_chunk_driver_groups_and_many_api(gpu_codec, oracle_mod, tmp_path):
+    """encode-chunks pushes whole chunks through alice_codec_encode_many in groups; every .alc equals the
+    single-chunk encode, the tail chunk included; decode_many returns what FrameDecoder::decode returns."""
+    from alice_codec_amd import cli
+    w, h, c, n_frames = 40, 24, 8, 8 * 5 + 3          # five whole 8-frame chunks and a 3-frame tail
+    rgb = np.random.default_rng(9).integers(0, 256, w * h * n_frames * 3, dtype=np.uint8)
+    raw = tmp_path / "in.rgb"; rgb.tofile(raw)
+    assert cli.main(["encode-chunks", str(raw), "-o", str(tmp_path / "g"), "-W", str(w), "-H", str(h), "-c", str(c),
+                     "--in-flight", "2", "-q", "85", "-w", "cdf97"]) == 0
+    fb = w * h * 3
+    for k in range(6):
+        f = c if k < 5 else 3
+        part = rgb[k * c * fb:(k * c + f) * fb]
+        assert (tmp_path / f"g.{k:05d}.alc").read_bytes() == oracle_mod.encode(part, w, h, f, 85, 1), k
+    enc = gpu_codec.FrameEncoder.with_wavelet(85, gpu_codec.WaveletType.Cdf97)
+    chunks = gpu_codec.encode_many(enc, rgb[:5 * c * fb], w, h, c)
+    assert [ch.to_bytes() for ch in chunks] == [oracle_mod.encode(rgb[k * c * fb:(k + 1) * c * fb], w, h, c, 85, 1) for k in range(5)]
+    dec = gpu_codec.decode_many(chunks)
+    for k in range(5):
+        assert np.array_equal(dec[k], oracle_mod.decode(chunks[k].to_bytes())), k
+    with pytest.raises(gpu_codec.CodecError):
+        gpu_codec.encode_many(enc, rgb[:5 * c * fb + 3], w, h, c)
