@@ -152,6 +152,8 @@ def main() -> None:
     rgb = torch.empty((B, F, H, W, 3), dtype=torch.uint8, device=dev)
     for i in range(B):
         rgb[i] = synth_chunk(dev, rank * B + i)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()   # the generator's temporaries: rank 0 of an 8-GPU run needs the room for the gathered blobs
     out = torch.empty_like(rgb) if args.separate_output else None
     batch = ac.Batch(W, H, F, B, QUALITY, WAVELET)
     stream = torch.cuda.current_stream().cuda_stream
