@@ -447,9 +447,10 @@ int encode_collect(EncodeWork& w, hipStream_t st, std::vector<RansResult>& res) 
     }
     if (getenv("ALICE_CODEC_DEBUG"))
         for (size_t i = 0; i < res.size(); ++i)
-            fprintf(stderr, "[alice] encode chain %zu: %llu bytes, %.1f Mcycles, %.1f ms of 100 MHz ticks => %.2f GHz\n", i, res[i].len,
-                    res[i].fast_tiles * 1024.0 / 1e6, res[i].slow_tiles * 1024.0 / 1e5,
-                    res[i].slow_tiles ? (res[i].fast_tiles / (double)res[i].slow_tiles) * 0.1 : 0.0);
+            fprintf(stderr, "[alice] encode chain %zu: %llu bytes, %.1f Mcycles, %.1f ms of 100 MHz ticks => %.2f GHz, xcc %u se %u cu %u simd %u\n", i, res[i].len,
+                    res[i].cycles_k * 1024.0 / 1e6, res[i].ticks_k * 1024.0 / 1e5,
+                    res[i].ticks_k ? (res[i].cycles_k / (double)res[i].ticks_k) * 0.1 : 0.0,
+                    res[i].xcc_id & 15u, (res[i].hw_id >> 13) & 7u, (res[i].hw_id >> 8) & 15u, (res[i].hw_id >> 4) & 3u);
     for (auto& r : res)
         if (r.flags & kRansOverflow) return -1;  // caller retries with the worst-case capacity
     return kOk;
@@ -548,8 +549,9 @@ int decode_collect(DecodeWork& w, hipStream_t st) {
         if (r.flags & kRansInternal) return fail(kInternal, "rANS decode table invariant violated");
     if (getenv("ALICE_CODEC_DEBUG"))
         for (size_t i = 0; i < res.size(); ++i)
-            fprintf(stderr, "[alice] decode chain %zu: consumed %llu bytes, fast tiles %u, slow tiles %u\n", i, res[i].len,
-                    res[i].fast_tiles, res[i].slow_tiles);
+            fprintf(stderr, "[alice] decode chain %zu: consumed %llu bytes, fast tiles %u, slow tiles %u, %.1f Mcycles, xcc %u se %u cu %u simd %u\n", i, res[i].len,
+                    res[i].fast_tiles, res[i].slow_tiles, res[i].cycles_k * 1024.0 / 1e6,
+                    res[i].xcc_id & 15u, (res[i].hw_id >> 13) & 7u, (res[i].hw_id >> 8) & 15u, (res[i].hw_id >> 4) & 3u);
     return kOk;
 }
 

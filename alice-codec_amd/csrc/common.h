@@ -72,12 +72,28 @@ static_assert(sizeof(RansEncEntry) == 32, "RansEncEntry must be 32 bytes");
 constexpr uint32_t kTableNeedsGeneric = 1u;   // a symbol present in the data has freq > 4096
 constexpr uint32_t kTableDiverges = 2u;       // a symbol present in the data has freq == 0
 constexpr uint32_t kTableVerified = 16u;      // built from the data's own histogram: the two flags above are authoritative
+constexpr uint32_t kTableDecBig = 32u;        // a symbol of frequency 4096 owns slots (its packed decode entry needs x >= 1)
+constexpr uint32_t kTableDecExact = 64u;      // a symbol of frequency > 4096 owns slots: the packed decode entries cannot
+                                              // express it, the decoder takes its exact loop for every symbol
+
+// Decoder view of a table, one entry per slot (x & 4095), laid out for the chain kernel: the decode update
+// x' = freq * (x >> 12) + slot - cum is evaluated as umulhi(F', x) + B' (rans.hip).  The chain wave copies F' and B'
+// into 128 VGPRs at the start of every 4096-symbol tile straight from here (L2-resident, 32 KB per chain), so they
+// never occupy LDS.
+struct RansDecSlots {
+    uint32_t ftab[kProbScale];    // F'[slot] = freq << 20         (0xFFFFFFFF for freq 4096)
+    uint32_t btab[kProbScale];    // B'[slot] = slot - cum - ((freq * slot) >> 12)
+    uint32_t symtab[256];         // freq | cum << 16 per symbol (exact loop)
+    uint8_t c2s[kProbScale];      // cum_to_sym, src/rans.rs:135-144
+};
 
 struct RansTable {
     RansEncEntry enc[256];
     uint32_t flags;
     uint32_t pad[7];
+    RansDecSlots dec;
 };
+static_assert(sizeof(RansTable) % 32 == 0 && offsetof(RansTable, dec) % 32 == 0, "RansTable layout");
 
 struct ChunkDims {
     uint32_t w, h, f;     // as given

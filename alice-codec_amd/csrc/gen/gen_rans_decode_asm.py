@@ -19,8 +19,11 @@ Register plan (all literal, all listed as clobbers by the including statement):
   s67 F'   s69 B'   s70 product   s71 shift   s72 valid window bits - 33   s73 next window dword
   s74 blocks left   s75 byte-swap selector   s76 row   s77 shift of the odd symbol   s78 scratch
   s80..s100   renormalisation shift (0, 8 or 16) by count-leading-zeros of the state
-Operands: %[ta] %[tb] %[wa] (VGPR: per-lane LDS byte addresses), %[ra] (VGPR in/out: record address, 2 B per lane),
+Operands: %[tp] (SGPR pair: the chain's RansDecSlots in global memory, F' then B'), %[l4] (VGPR: 4 * lane),
+          %[wa] (VGPR: per-lane LDS byte address of the window), %[ra] (VGPR in/out: record address, 2 B per lane),
           %[xi] %[pi] %[nb] (SGPR in), %[xo] %[po] (SGPR out).
+The tables are re-read from global memory (L2) at the top of every tile: 128 loads per 4096 symbols, well under 1 % of a
+tile's time, and nothing of them lives in LDS, which is what bounds the number of chains a CU can host.
 """
 import os
 
@@ -30,14 +33,22 @@ REC = 192 + WIN_ROWS
 L = []
 def e(s): L.append(s)
 
-for r in range(64):
-    e(f"ds_read_b32 v{64 + r}, %[ta] offset:{256 * r}")
-for r in range(64):
-    e(f"ds_read_b32 v{128 + r}, %[tb] offset:{256 * r}")
+def table_loads(emit):
+    """F' then B' (contiguous in RansDecSlots): 128 rows of 256 bytes, row r into v[64 + r], lane l <- dword 64 r + l.
+    global_load's immediate offset is 13 bits signed, so the scalar base moves on every 16 rows (the address is read
+    when the load issues)."""
+    emit("s_mov_b64 s[64:65], %[tp]")
+    for r in range(128):
+        emit(f"global_load_dword v{64 + r}, %[l4], s[64:65] offset:{256 * (r % 16)}")
+        if r % 16 == 15 and r != 127:
+            emit("s_add_u32 s64, s64, 0x1000")
+            emit("s_addc_u32 s65, s65, 0")
+
+table_loads(e)
 for r in range(WIN_ROWS):
     e(f"ds_read_b32 v{192 + r}, %[wa] offset:{256 * r}")
 e("s_mov_b32 s75, 0x00010203")
-e("s_waitcnt lgkmcnt(0)")
+e("s_waitcnt vmcnt(0) lgkmcnt(0)")
 for r in range(WIN_ROWS):
     e(f"v_perm_b32 v{192 + r}, v{192 + r}, v{192 + r}, s75")
 for c in range(21):
@@ -113,13 +124,10 @@ e("s_waitcnt lgkmcnt(0)")
 # (src/rans.rs:365-368) and the state simply evolves: the same lookup and update, no window, no shift.
 D = []
 def d(s): D.append(s)
-for r in range(64):
-    d(f"ds_read_b32 v{64 + r}, %[ta] offset:{256 * r}")
-for r in range(64):
-    d(f"ds_read_b32 v{128 + r}, %[tb] offset:{256 * r}")
+table_loads(d)
 d("s_mov_b32 s61, %[xi]")
 d("s_mov_b32 s74, %[nb]")
-d("s_waitcnt lgkmcnt(0)")
+d("s_waitcnt vmcnt(0)")
 d("2:")
 for lane in range(64):
     d("s_bfe_u32 s76, s61, 0x60006")
@@ -137,7 +145,7 @@ d("s_cmp_lg_u32 s74, 0")
 d("s_cbranch_scc1 2b")
 d("s_mov_b32 %[xo], s61")
 d("s_waitcnt lgkmcnt(0)")
-dry_clob = ["memory", "scc", "m0", "s61", "s67", "s69", "s70", "s74", "s76"] + [f"v{r}" for r in range(64, 192)] + [f"v{REC}"]
+dry_clob = ["memory", "scc", "m0", "s61", "s64", "s65", "s67", "s69", "s70", "s74", "s76"] + [f"v{r}" for r in range(64, 192)] + [f"v{REC}"]
 
 clob = ["memory", "scc", "m0"] + [f"s{i}" for i in range(60, 79)] + [f"s{80 + c}" for c in range(21)]
 clob += [f"v{r}" for r in range(64, REC + 1)]

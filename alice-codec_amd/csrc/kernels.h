@@ -14,6 +14,10 @@ struct RansResult {
     uint32_t final_state;
     uint32_t fast_tiles;      // decode: tiles taken by the scalar fast path / by the exact lane loop
     uint32_t slow_tiles;
+    // diagnostics (ALICE_CODEC_DEBUG): shader cycles and 100 MHz ticks the chain took (kibi-units), where it ran
+    uint32_t cycles_k, ticks_k;
+    uint32_t hw_id;           // HW_REG_HW_ID: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]
+    uint32_t xcc_id;          // HW_REG_XCC_ID [3:0]
 };
 
 struct RansDecodeDesc {

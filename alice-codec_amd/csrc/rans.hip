@@ -112,16 +112,55 @@ __device__ inline RansEncEntry make_enc_entry(uint32_t f, uint32_t c) {
     return e;
 }
 
+// Decoder slot tables, filled as the reference fills cum_to_sym (src/rans.rs:135-144): zero-initialised, then symbol by
+// symbol in index order over [cum, min(cum + freq, 4096)), so the LAST symbol that covers a slot owns it (ranges built
+// from a histogram are disjoint; caller-supplied tables may overlap) and an uncovered slot belongs to symbol 0.
+// Called by all 256 threads of the block, s = threadIdx.x holding symbol s; scratch: 768 u32 in LDS.  Returns the
+// kTableDec* flags of the slots this thread filled.
+__device__ inline uint32_t build_dec_slots(uint32_t f, uint32_t c, uint32_t* scratch, RansDecSlots* __restrict__ out) {
+    const int s = threadIdx.x;
+    uint32_t end = c + f;
+    if (end > kProbScale) end = kProbScale;
+    __syncthreads();
+    scratch[s] = c;
+    scratch[256 + s] = c < end ? end : c;   // empty range when cum >= 4096 or freq == 0
+    scratch[512 + s] = f;
+    out->symtab[s] = (f & 0xFFFFu) | (c << 16);
+    __syncthreads();
+    uint32_t fl = 0u;
+    for (uint32_t slot = (uint32_t)s; slot < kProbScale; slot += 256u) {
+        uint32_t owner = 0u;
+        for (uint32_t k = 0; k < 256u; ++k)
+            if (slot >= scratch[k] && slot < scratch[256 + k]) owner = k;
+        const uint32_t fo = scratch[512 + owner], co = scratch[owner];
+        // x' = freq * (x >> 12) + slot - cum = umulhi(F', x) + B' with F' = freq << 20 and
+        // B' = slot - cum - ((freq * slot) >> 12): with x = 4096 h + slot, floor(freq * x / 4096) =
+        // freq * h + floor(freq * slot / 4096).  freq = 4096 would overflow F'; there F' = 2^32 - 1
+        // (umulhi gives x - 1 for x >= 1) and B' carries the + 1.
+        uint32_t fe, be;
+        if (fo >= kProbScale) {
+            fe = 0xFFFFFFFFu; be = (slot - co) - slot + 1u;
+            fl |= fo > kProbScale ? kTableDecExact : kTableDecBig;
+        } else {
+            fe = fo << 20; be = (slot - co) - ((fo * slot) >> kProbBits);
+        }
+        out->ftab[slot] = fe;
+        out->btab[slot] = be;
+        out->c2s[slot] = (uint8_t)owner;
+    }
+    return fl;
+}
+
 __global__ __launch_bounds__(256) void rans_table_kernel(const uint32_t* __restrict__ hist,
                                                          RansTable* __restrict__ tables) {
-    __shared__ uint32_t scratch[256];
+    __shared__ uint32_t scratch[768];
     const int chain = blockIdx.x;
     const int s = threadIdx.x;
     const uint32_t count = hist[(size_t)chain * 256 + s];
     uint32_t f, c;
     freq_table_256(count, scratch, f, c);
     tables[chain].enc[s] = make_enc_entry(f, c);
-    uint32_t fl = 0u;
+    uint32_t fl = build_dec_slots(f, c, scratch, &tables[chain].dec);
     if (count > 0u && f == 0u) fl |= kTableDiverges;
     if (count > 0u && f > kProbScale) fl |= kTableNeedsGeneric;
     __shared__ uint32_t flags_sh;
@@ -136,9 +175,15 @@ __global__ __launch_bounds__(256) void rans_table_kernel(const uint32_t* __restr
 __global__ __launch_bounds__(256) void rans_table_from_arrays_kernel(const uint16_t* __restrict__ cum,
                                                                      const uint16_t* __restrict__ freq,
                                                                      RansTable* __restrict__ table) {
+    __shared__ uint32_t scratch[768];
+    __shared__ uint32_t flags_sh;
     const int s = threadIdx.x;
+    if (s == 0) flags_sh = 0u;
     table->enc[s] = make_enc_entry(freq[s], cum[s]);
-    if (s == 0) table->flags = 0u;
+    const uint32_t fl = build_dec_slots(freq[s], cum[s], scratch, &table->dec);
+    if (fl) atomicOr(&flags_sh, fl);
+    __syncthreads();
+    if (s == 0) table->flags = flags_sh;
 }
 
 // ----------------------------------------------------------------------------------
@@ -183,6 +228,9 @@ __device__ __forceinline__ void ripple64(uint32_t& xin, uint32_t& xout, uint32_t
 #undef ALICE_RIPPLE_STEP
 }
 
+// kExclusive: the kernel claims more than half of the SIMD's 512 registers (an AGPR clobber; nothing uses them), so
+// the dispatcher cannot put two chains on one SIMD -- see launch_rans_encode.
+template <bool kExclusive>
 __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restrict__ sym_base,
                                                          unsigned long long sym_stride,
                                                          unsigned long long n_first,
@@ -197,6 +245,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
     __shared__ __attribute__((aligned(16))) uint8_t tile[kEncTile];
 
+    if constexpr (kExclusive) asm volatile("" ::: "a255");
     const int chain = blockIdx.x;
     const int lane = threadIdx.x;
     // chains from n_split on carry one symbol less (the sub-sequences of an interleaved stream)
@@ -218,7 +267,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         tab_b[s] = make_uint4((uint32_t)e.g, e.cbias, e.freq, e.cum);
     }
 
-    const bool table_clean = tbl->flags == kTableVerified;  // uniform
+    const bool table_clean = (tbl->flags & (kTableVerified | kTableNeedsGeneric | kTableDiverges)) == kTableVerified;  // uniform
     uint32_t x = kRansL;  // RansEncoder::new, src/rans.rs:249-254
     const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
     unsigned long long written = 0ull;
@@ -381,9 +430,12 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         results[chain].len = written;
         results[chain].flags = flags;
         results[chain].final_state = x;
-        // diagnostics: shader cycles and 100 MHz ticks spent in the chain (kibi-units)
-        results[chain].fast_tiles = (uint32_t)((clock64() - clk0) >> 10);
-        results[chain].slow_tiles = (uint32_t)((wall_clock64() - rt0) >> 10);
+        results[chain].fast_tiles = 0u;
+        results[chain].slow_tiles = 0u;
+        results[chain].cycles_k = (uint32_t)((clock64() - clk0) >> 10);
+        results[chain].ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
+        results[chain].hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        results[chain].xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 }
 
@@ -418,81 +470,62 @@ constexpr int kDecWinLds = kDecWinBytes;
 // and once per two symbols a test whether the 64-bit byte window needs its next dword.
 #include "rans_decode_tile.inc"
 
-// Decodes nblk*64 symbols on the fast path.  tab_addr / win_addr / rec_addr are this lane's LDS byte
-// addresses (base + 4*lane; the record is 2 bytes per lane).  pos = byte offset of the next stream byte inside the window.
-__device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, uint32_t ftab_addr, uint32_t btab_addr,
+// Decodes nblk*64 symbols on the fast path.  slots = the chain's RansDecSlots (F' at byte 0, B' at byte 16384, read with
+// 128 global loads per lane: lane4 = 4 * lane); win_addr / rec_addr are this lane's LDS byte addresses (base + 4*lane;
+// the record is 2 bytes per lane).  pos = byte offset of the next stream byte inside the window.
+__device__ __forceinline__ void dec_tile_fast(uint32_t& x, uint32_t& pos, const RansDecSlots* slots, uint32_t lane4,
                                               uint32_t win_addr, uint32_t rec_addr, uint32_t nblk) {
     uint32_t xo, po;
     asm volatile(ALICE_DEC_TILE_ASM
                  : [xo] "=&s"(xo), [po] "=&s"(po), [ra] "+v"(rec_addr)
-                 : [xi] "s"(x), [pi] "s"(pos), [nb] "s"(nblk), [ta] "v"(ftab_addr), [tb] "v"(btab_addr), [wa] "v"(win_addr)
+                 : [xi] "s"(x), [pi] "s"(pos), [nb] "s"(nblk), [tp] "s"(slots), [l4] "v"(lane4), [wa] "v"(win_addr)
                  : ALICE_DEC_TILE_CLOBBERS);
     x = xo;
     pos = po;
 }
 
 // The same lookup and update with the stream exhausted: nothing is shifted in any more (src/rans.rs:365-368 reads
-// no byte once pos == len), the state just evolves.  Needs a table without a frequency of 4096 (its F' encoding is
-// only right for x >= 1, and a dry state may reach 0).
-__device__ __forceinline__ void dec_tile_dry(uint32_t& x, uint32_t ftab_addr, uint32_t btab_addr, uint32_t rec_addr, uint32_t nblk) {
+// no byte once pos == len), the state just evolves.  A frequency-4096 entry is only right for x >= 1 (see
+// build_dec_slots); the caller checks that.
+__device__ __forceinline__ void dec_tile_dry(uint32_t& x, const RansDecSlots* slots, uint32_t lane4, uint32_t rec_addr, uint32_t nblk) {
     uint32_t xo;
     asm volatile(ALICE_DEC_DRY_TILE_ASM
                  : [xo] "=&s"(xo), [ra] "+v"(rec_addr)
-                 : [xi] "s"(x), [nb] "s"(nblk), [ta] "v"(ftab_addr), [tb] "v"(btab_addr)
+                 : [xi] "s"(x), [nb] "s"(nblk), [tp] "s"(slots), [l4] "v"(lane4)
                  : ALICE_DEC_DRY_TILE_CLOBBERS);
     x = xo;
 }
 
+// LDS per chain: cum_to_sym 4 KB + exact-loop symbol table 1 KB + stream window 8.25 KB + state record 8 KB
+// (the exact loop's output bytes share the record's space) = 21.3 KB.  The launcher adds dynamic LDS so that at most
+// four (up to 1024 chains: one per SIMD) or seven chains share a CU.
+template <bool kExclusive>
 __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* __restrict__ descs,
                                                          RansResult* __restrict__ results) {
-    // x' = freq * (x >> 12) + slot - cum is evaluated as umulhi(F', x) + B' with F' = freq << 20 and
-    // B' = slot - cum - ((freq * slot) >> 12): with x = 4096 h + slot, floor(freq * x / 4096) =
-    // freq * h + floor(freq * slot / 4096), which saves the shift in the chain.  freq = 4096 would overflow
-    // F'; there F' = 2^32 - 1 (umulhi gives x - 1 for x >= 1) and B' carries the + 1.
-    __shared__ uint32_t ftab[kProbScale];
-    __shared__ uint32_t btab[kProbScale];
-    __shared__ uint8_t c2s[kProbScale];                               // cum_to_sym
-    __shared__ uint32_t symtab[256];                                  // freq | cum << 16 (exact slow path)
+    if constexpr (kExclusive) asm volatile("" ::: "a63");   // 226 VGPRs + 64 AGPRs > 256: one chain per SIMD
+    __shared__ __attribute__((aligned(16))) uint8_t c2s[kProbScale];                  // cum_to_sym
+    __shared__ uint32_t symtab[256];                                                    // freq | cum << 16 (exact loop)
     __shared__ __attribute__((aligned(16))) uint8_t win[kDecWinLds];
-    __shared__ __attribute__((aligned(16))) uint16_t rec[kDecTile];   // low 16 bits of the pre-update states
-    __shared__ __attribute__((aligned(16))) uint8_t obuf[kDecTile];
+    __shared__ __attribute__((aligned(16))) uint16_t rec[kDecTile];                     // low 16 bits of the pre-update states
+    uint8_t* const obuf = (uint8_t*)rec;                                                // exact loop / unaligned output staging
 
     const RansDecodeDesc d = descs[blockIdx.x];
     const int lane = threadIdx.x;
+    const RansDecSlots* const slots = &d.table->dec;
     uint32_t flags = 0u;
-
-    auto entry = [](uint32_t f, uint32_t c, uint32_t s, uint32_t& fo, uint32_t& bo) {
-        if (f >= kProbScale) { fo = 0xFFFFFFFFu; bo = (s - c) - s + 1u; }           // only f == 4096 can own slots
-        else { fo = f << 20; bo = (s - c) - ((f * s) >> kProbBits); }
-    };
-    // cum_to_sym is zero-initialised (src/rans.rs:135): default every slot to symbol 0
-    bool big_freq;   // some symbol has freq >= 4096 (uniform)
-    {
-        const uint32_t f0 = d.table->enc[0].freq, c0 = d.table->enc[0].cum;
-        bool big = f0 >= kProbScale;
-        for (int s = lane; s < (int)kProbScale; s += 64) {
-            c2s[s] = 0;
-            entry(f0, c0, (uint32_t)s, ftab[s], btab[s]);
-        }
-        for (int k = 0; k < 4; ++k) {
-            const int sym = lane * 4 + k;
-            symtab[sym] = (d.table->enc[sym].freq & 0xFFFFu) | (d.table->enc[sym].cum << 16);
-        }
-        __syncthreads();
-        // symbols in index order; their slot ranges are disjoint (cum is a running sum), src/rans.rs:136-144
-        for (int k = 0; k < 4; ++k) {
-            const int sym = lane * 4 + k;
-            const uint32_t f = d.table->enc[sym].freq, c = d.table->enc[sym].cum;
-            big |= f >= kProbScale && c < kProbScale;   // only an entry that owns slots matters (the wrapped symbol 255 does not)
-            uint32_t end = c + f;
-            if (end > kProbScale) end = kProbScale;
-            for (uint32_t s = c; s < end; ++s) {
-                c2s[s] = (uint8_t)sym;
-                entry(f, c, s, ftab[s], btab[s]);
-            }
-        }
-        big_freq = __ballot(big) != 0ull;
-        __syncthreads();
+    const uint32_t tflags = d.table->flags;
+    const bool big_freq = (tflags & kTableDecBig) != 0u;   // some slot belongs to a symbol of frequency 4096 (uniform)
+    const bool exact_only = (tflags & kTableDecExact) != 0u;
+    for (int i = lane; i < (int)kProbScale / 16; i += 64) ((uint4*)c2s)[i] = ((const uint4*)slots->c2s)[i];
+    for (int i = lane; i < 256; i += 64) symtab[i] = slots->symtab[i];
+    __syncthreads();
+    bool slot0_big = false, one_owner = false;   // uniform
+    if (big_freq) {
+        const uint32_t o0 = c2s[0];
+        slot0_big = symtab[o0] == kProbScale;     // freq 4096, cum 0
+        bool same = true;
+        for (int i = lane; i < (int)kProbScale; i += 64) same &= c2s[i] == o0;
+        one_owner = __ballot(!same) == 0ull;
     }
 
     // RansDecoder::new (src/rans.rs:330-347)
@@ -504,18 +537,22 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         pos = 4ull;
     }
     bool pending = false;  // renormalisation owed by the previous symbol
+    const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
     unsigned long long done = 0ull;
     uint32_t n_fast = 0u, n_slow = 0u;
 
     while (done < d.n) {
         const unsigned long long remain = d.n - done;
         const uint32_t want = remain < (unsigned long long)kDecTile ? (uint32_t)remain : (uint32_t)kDecTile;
-        if (want == (uint32_t)kDecTile && pos >= len && !big_freq) {
+        // A frequency-4096 entry is wrong for x = 0 only (build_dec_slots), and x = 0 looks up slot 0: the dry tile is
+        // safe unless such a symbol owns slot 0; if it does and owns every slot, x' = x - cum = x and a non-zero state
+        // stays what it is.
+        const bool dry_ok = !exact_only && (!slot0_big || (one_owner && x != 0u));
+        if (want == (uint32_t)kDecTile && pos >= len && dry_ok) {
             // stream exhausted (a desynchronised decoder runs dry long before its last symbol): no window, no shifts
             uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
             __syncthreads();
-            dec_tile_dry(xs, (uint32_t)(uintptr_t)ftab + 4u * lane, (uint32_t)(uintptr_t)btab + 4u * lane,
-                         (uint32_t)(uintptr_t)rec + 2u * lane, (uint32_t)kDecBlocks);
+            dec_tile_dry(xs, slots, 4u * lane, (uint32_t)(uintptr_t)rec + 2u * lane, (uint32_t)kDecBlocks);
             x = xs;
             __syncthreads();
             const bool out_al = (((uintptr_t)(d.out + done)) & 3u) == 0u;
@@ -565,7 +602,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         // turns out to have consumed padding (it ran dry part-way) its result is dropped and the exact loop redoes
         // the tile from the saved state.  A desynchronised decoder that eats a fraction of a bit per symbol spends
         // hundreds of tiles inside the last window; they all stay on the fast path this way.
-        bool fast = (want == (uint32_t)kDecTile) && pos < len;
+        bool fast = (want == (uint32_t)kDecTile) && pos < len && !exact_only;
         const uint32_t x_save = x;
         const unsigned long long pos_save = pos;
         const bool pending_save = pending;
@@ -582,8 +619,8 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             uint32_t prel = (uint32_t)(pos - wbase);
             uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
             prel = (uint32_t)__builtin_amdgcn_readfirstlane((int)prel);
-            dec_tile_fast(xs, prel, (uint32_t)(uintptr_t)ftab + 4u * lane, (uint32_t)(uintptr_t)btab + 4u * lane,
-                          (uint32_t)(uintptr_t)win + 4u * lane, (uint32_t)(uintptr_t)rec + 2u * lane, (uint32_t)kDecBlocks);
+            dec_tile_fast(xs, prel, slots, 4u * lane, (uint32_t)(uintptr_t)win + 4u * lane,
+                          (uint32_t)(uintptr_t)rec + 2u * lane, (uint32_t)kDecBlocks);
             x = xs;
             pos = wbase + prel;
             pending = false;  // the fast path renormalises right after each update
@@ -650,6 +687,10 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         results[blockIdx.x].final_state = x;
         results[blockIdx.x].fast_tiles = n_fast;
         results[blockIdx.x].slow_tiles = n_slow;
+        results[blockIdx.x].cycles_k = (uint32_t)((clock64() - clk0) >> 10);
+        results[blockIdx.x].ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
+        results[blockIdx.x].hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        results[blockIdx.x].xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 }
 
@@ -667,11 +708,24 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
     hipLaunchKernelGGL(rans_table_from_arrays_kernel, dim3(1), dim3(256), 0, st, d_cum, d_freq, d_table);
 }
 
+// A chain is one wavefront that runs for seconds, and waves never migrate: two chains that the dispatcher puts on one
+// SIMD while another SIMD idles run at 0.7 / 1.0 of their speed to the end (measured: with 900 chains, 4 single-wave
+// workgroups per CU, a tenth of the SIMDs hosted two encoder waves).  Up to 1024 chains the kernels therefore claim more
+// than half of a SIMD's register file, which leaves the dispatcher no choice but one chain per SIMD.  Beyond that two
+// chains per SIMD are wanted (together they run at about 1.5x the rate of one); dynamic LDS that the kernels never touch
+// then caps the workgroups per CU at 8 so that the surplus spreads over all CUs.
+static unsigned chain_lds_pad(int n_chains, unsigned static_lds) {
+    if (n_chains <= 1024 || n_chains > 2048) return 0u;
+    const unsigned want = 163840u / 8u - 1024u;   // a ninth workgroup no longer fits (160 KB of LDS per CU)
+    return want > static_lds ? want - static_lds : 0u;
+}
+
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
                         uint64_t group_stride, uint64_t group_head, unsigned n_split) {
     if (n_chains <= 0) return;
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(n_chains), dim3(64), 0, st, d_sym,
+    auto kern = n_chains <= 1024 ? rans_encode_kernel<true> : rans_encode_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, 9216u), st, d_sym,
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
                        (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, n_split,
                        d_results);
@@ -679,7 +733,8 @@ void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, c
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {
     if (n_chains <= 0) return;
-    hipLaunchKernelGGL(rans_decode_kernel, dim3(n_chains), dim3(64), 0, st, d_descs, d_results);
+    auto kern = n_chains <= 1024 ? rans_decode_kernel<true> : rans_decode_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, 21776u + 256u), st, d_descs, d_results);
 }
 
 }  // namespace alice

@@ -82,6 +82,78 @@ def gather_alc_start(packed: Optional[torch.Tensor], sizes: torch.Tensor, dst: i
     return PendingGather(reqs, None)
 
 
+class DeviceView:
+    """Zero-copy torch view of library-owned device memory (the batch's `.alc` buffers): torch.as_tensor() reads the
+    CUDA array interface, which HIP tensors share."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    def tensor(self, device) -> torch.Tensor:
+        return torch.as_tensor(self, device=device)
+
+
+def stream_alc_to_root(get_chunk: Callable[[int], torch.Tensor], sizes: torch.Tensor,
+                       sink: Callable[[int, int, torch.Tensor], None], dst: int = 0,
+                       group: Optional[dist.ProcessGroup] = None, device=None, depth: int = 2) -> Optional[torch.Tensor]:
+    """The gather without a blob on the root: every rank's chunks pass through a small ring of receive slots on rank
+    `dst` and are handed to `sink(rank, chunk_index, bytes)` one at a time (bench.py: a copy on to pinned host memory;
+    a real front end: the file or socket the `.alc` stream goes to).  The root's HBM then holds `depth` slots per peer
+    (a slot = the largest chunk), not world x chunks x chunk size -- gather_alc_start() with 8 GPUs x 285 chunks x 0.11 GB
+    would need 250 GB on rank 0 and used to cap every rank's chunks in flight.
+
+    get_chunk(i): uint8 tensor holding this rank's chunk i in its first sizes[i] bytes (a view, e.g. DeviceView of the
+    batch's own buffer: nothing is packed or staged on the senders).  sizes: int64 [chunks_per_rank], the same count on
+    every rank.  The tensor given to `sink` is only valid during the call (device work it enqueues on the current stream
+    is ordered before the slot's next receive).  Chunk i of all peers travels in one grouped point-to-point batch: a
+    fan-in on the root's links, no ring, no collective on the data path.  Returns all_sizes [world, chunks] on the root."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = int(sizes.numel())
+    probe = get_chunk(0) if n else torch.empty(0, dtype=torch.uint8, device=device or "cpu")
+    dev = probe.device
+    sizes_d = sizes.to(dev, torch.int64)
+    all_sizes = [torch.empty_like(sizes_d) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes_d, group=group)
+    all_sizes_t = torch.stack(all_sizes).cpu()
+    if rank != dst:
+        for i in range(n):
+            m = int(all_sizes_t[rank, i])
+            if m > 0:
+                for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, get_chunk(i)[:m], dst, group)]):
+                    r.wait()
+        return None
+    slot_bytes = int(all_sizes_t.max()) if all_sizes_t.numel() else 0
+    peers = [r for r in range(world) if r != dst]
+    ring = {r: [torch.empty(max(slot_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(depth)] for r in peers}
+    inflight: list = []   # (chunk index, [(peer, slot view)], requests)
+
+    def post(i: int):
+        ops, views = [], []
+        for r in peers:
+            m = int(all_sizes_t[r, i])
+            if m > 0:
+                v = ring[r][i % depth][:m]
+                ops.append(dist.P2POp(dist.irecv, v, r, group))
+                views.append((r, v))
+        inflight.append((i, views, dist.batch_isend_irecv(ops) if ops else []))
+
+    for i in range(min(depth - 1, n)):
+        post(i)
+    for i in range(n):
+        if i + depth - 1 < n:
+            post(i + depth - 1)   # its slots were handed to the sink `depth` chunks ago
+        m = int(all_sizes_t[dst, i])
+        if m > 0:
+            sink(dst, i, get_chunk(i)[:m])
+        j, views, reqs = inflight.pop(0)
+        for r in reqs:
+            r.wait()
+        for r, v in views:
+            sink(r, j, v)
+    return all_sizes_t
+
+
 def split_blob(blob: torch.Tensor, all_sizes: torch.Tensor) -> List[bytes]:
     """Cuts the gathered blob back into individual `.alc` byte strings (rank-major, chunk-major)."""
     out, off = [], 0

@@ -66,6 +66,62 @@ def test_gather_alc_world2(chunks_total):
     assert ret.get(timeout=5) is True
 
 
+def _stream_worker(rank, world, port, per_rank, ret):
+    """The drained variant (multi.stream_alc_to_root): no blob on the root, chunks pass through a two-slot ring per peer
+    and reach a sink one by one; chunk sizes differ, one rank holds an empty chunk."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as o
+    from alice_codec_amd import multi
+
+    def blob_of(r, i):
+        if r == 1 and i == 1:
+            return b""                                   # a rank with nothing to send for one chunk
+        w, h, f = 8 + 2 * i, 6 + r, 2 + (i & 1)
+        rgb = np.random.default_rng(100 * r + i).integers(0, 256, w * h * f * 3, dtype=np.uint8)
+        return o.encode(rgb, w, h, f, 80, (r + i) % 3)
+
+    mine = [blob_of(rank, i) for i in range(per_rank)]
+    bufs = [torch.from_numpy(np.frombuffer(b + bytes(32), np.uint8).copy()) for b in mine]   # views longer than the chunk
+    sizes = torch.tensor([len(b) for b in mine], dtype=torch.int64)
+    got = {}
+    order = []
+
+    def sink(r, i, t):
+        got[(r, i)] = t.numpy().tobytes()   # the view is only valid during the call
+        order.append((r, i))
+
+    all_sizes = multi.stream_alc_to_root(lambda i: bufs[i], sizes, sink, dst=0)
+    if rank == 0:
+        ok = all_sizes.shape == (world, per_rank)
+        for r in range(world):
+            for i in range(per_rank):
+                want = blob_of(r, i)
+                ok &= int(all_sizes[r, i]) == len(want)
+                ok &= (got.get((r, i), b"") == want)
+        ok &= len(got) == sum(1 for r in range(world) for i in range(per_rank) if blob_of(r, i))
+        ok &= [i for _, i in order] == sorted(i for _, i in order)   # chunk-major: what a stream writer wants
+        ret.put(bool(ok))
+    else:
+        assert all_sizes is None and not got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,per_rank", [(2, 5), (3, 1)])
+def test_stream_alc_to_root(world, per_rank):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, per_rank, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert ret.get(timeout=5) is True
+
+
 def test_shard_chunks_partition():
     from alice_codec_amd import multi  # noqa
     for world in (1, 2, 3, 8):
