@@ -120,6 +120,8 @@ def load_library() -> C.CDLL:
         "alice_codec_device_count": (C.c_int, []),
         "alice_codec_set_device": (C.c_int, [C.c_int]),
         "alice_codec_trim": (None, []),
+        "alice_codec_test_force_first_cap": (None, [C.c_uint64]),
+        "alice_codec_test_last_decode_stats": (None, [_u32p]),
         "alice_codec_encoder_create_ex": (vp, [C.c_uint8, C.c_uint8]),
         "alice_codec_encoder_quality": (C.c_uint8, [vp]),
         "alice_codec_encoder_wavelet": (C.c_uint8, [vp]),
@@ -308,7 +310,11 @@ class FrameEncoder:
 
     def __init__(self, quality: int, wavelet_type: WaveletType = WaveletType.Cdf53):
         lib = load_library()
-        self.quality = int(quality) & 0xFF
+        # the reference takes a u8 (src/pipeline.rs:347): an out-of-range value is a caller error there (clap / PyO3
+        # refuse it), never a silent wrap
+        if not 0 <= int(quality) <= 255:
+            raise ValueError(f"quality must fit a u8 (0..255), got {quality}")
+        self.quality = int(quality)
         self.wavelet_type = WaveletType(wavelet_type)
         self._h = lib.alice_codec_encoder_create_ex(self.quality, int(self.wavelet_type))
         if not self._h:

@@ -86,6 +86,14 @@ def cmd_info(a) -> None:
     print(f"  Ratio:       {ratio * 100:.1f}%")
 
 
+def _u8(text: str) -> int:
+    """clap parses `quality: u8` (src/bin/main.rs:44-46): 300 or -1 is a usage error, not quality 44 or 255."""
+    v = int(text)
+    if not 0 <= v <= 255:
+        raise argparse.ArgumentTypeError(f"{text} is not in 0..255")
+    return v
+
+
 def main(argv=None) -> int:
     p = argparse.ArgumentParser(prog="alice-codec", description="ALICE-Codec: 3D wavelet video codec (MI355X path)")
     sub = p.add_subparsers(dest="command", required=True)
@@ -100,7 +108,7 @@ def main(argv=None) -> int:
         else:
             e.add_argument("-c", "--chunk", type=int, default=DEFAULT_CHUNK_SIZE)
             e.add_argument("--in-flight", type=int, default=16, help="chunks encoded per call (GPU memory: about 2.4x the raw size of a chunk each)")
-        e.add_argument("-q", "--quality", type=int, default=90)
+        e.add_argument("-q", "--quality", type=_u8, default=90)
         e.add_argument("-w", "--wavelet", default="cdf53")
     d = sub.add_parser("decode")
     d.add_argument("input")

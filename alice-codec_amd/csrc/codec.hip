@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,9 @@ void clear_error() { tl_err = kOk; tl_msg.clear(); }
 thread_local int tl_device = -1;         // -1: not chosen yet (device 0 on first use)
 thread_local hipStream_t tl_stream = nullptr;
 thread_local int tl_stream_device = -1;
+// stream the work of the current entry point runs on: buffers allocated meanwhile remember it and drain it before they
+// go back to the pool (an error return may leave kernels in flight on them)
+thread_local hipStream_t tl_scope_stream = nullptr;
 
 int ensure_device() {
     int count = 0;
@@ -85,6 +89,7 @@ int get_stream(hipStream_t* out) {
         tl_stream_device = tl_device;
     }
     *out = tl_stream;
+    tl_scope_stream = tl_stream;
     return kOk;
 }
 
@@ -117,12 +122,13 @@ public:
         *out = p;
         return kOk;
     }
-    void release(void* p, size_t bytes) {
+    // dev = the device the block was allocated on (the releasing thread may have moved on to another one)
+    void release(void* p, size_t bytes, int dev) {
         if (!p) return;
         const size_t b = bucket(bytes);
         std::lock_guard<std::mutex> g(mu_);
         if (cached_ + b > kMaxCached) { (void)hipFree(p); return; }
-        free_[{tl_device, b}].push_back(p);
+        free_[{dev, b}].push_back(p);
         cached_ += b;
     }
     void trim() {
@@ -156,6 +162,8 @@ DevicePool& pool() {
 struct DevBuf {
     void* p = nullptr;
     size_t n = 0;
+    int dev = 0;                // device the block lives on
+    hipStream_t st = nullptr;   // stream whose work may still touch it
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -164,11 +172,33 @@ struct DevBuf {
         reset();
         if (bytes == 0) bytes = 16;
         int rc = pool().alloc(bytes, &p);
-        if (rc == kOk) n = bytes;
+        if (rc == kOk) { n = bytes; dev = tl_device; st = tl_scope_stream; }
         return rc;
     }
-    void reset() { if (p) pool().release(p, n); p = nullptr; n = 0; }
+    // The pool is shared by all threads, each with a stream of its own: a block must be idle before another thread can
+    // get it.  On the normal paths the stream has been synchronised already and this returns at once.
+    void reset() {
+        if (p) {
+            if (st) (void)hipStreamSynchronize(st);
+            pool().release(p, n, dev);
+        }
+        p = nullptr; n = 0; st = nullptr;
+    }
     template <typename T> T* as() const { return (T*)p; }
+};
+
+// Entry points that work on an object tied to a device (a batch) switch this thread to it for the call.
+struct DeviceScope {
+    int saved;
+    bool ok;
+    explicit DeviceScope(int device) : saved(tl_device), ok(true) {
+        tl_device = device;
+        if (ensure_device() != kOk) ok = false;
+    }
+    ~DeviceScope() {
+        tl_device = saved;
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
 };
 
 #define TRY(expr) do { int rc__ = (expr); if (rc__ != kOk) return rc__; } while (0)
@@ -381,6 +411,13 @@ int forward_generic(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32
     return kOk;
 }
 
+std::atomic<uint64_t> g_test_first_cap{0};
+thread_local uint32_t tl_dec_stats[4] = {0, 0, 0, 0};   // last single-chain decode of this thread: fast tiles, exact tiles, path mask, bytes consumed
+void note_decode_stats(const RansResult& r) {
+    tl_dec_stats[0] = r.fast_tiles; tl_dec_stats[1] = r.slow_tiles; tl_dec_stats[2] = r.paths;
+    tl_dec_stats[3] = (uint32_t)(r.len > 0xFFFFFFFFull ? 0xFFFFFFFFull : r.len);
+}
+
 struct StageEvents {
     hipEvent_t ev[8] = {nullptr};
     bool ready = false;
@@ -418,8 +455,9 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
         HIP_TRY(hipStreamSynchronize(st));
         for (int c = 0; c < 3 * B; ++c) cap = std::max(cap, estimate_stream_cap(&hist[(size_t)c * 256], d.padded));
         cap = std::min(round_up(cap, 256), worst_cap(d));
-        // test hook: pretend the estimate was far too small, to exercise the overflow-and-retry path
-        if (getenv("ALICE_CODEC_TEST_TINY_CAP")) cap = 4352;
+        // test-only override (alice_codec_test_force_first_cap): pretend the estimate was far too small, to exercise
+        // the overflow-and-retry path
+        if (const uint64_t forced = g_test_first_cap.load(std::memory_order_relaxed)) cap = forced;
     }
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
@@ -863,6 +901,7 @@ int alice_codec_set_device(int device) {
     return ensure_device();
 }
 void alice_codec_trim(void) { pool().trim(); }
+void alice_codec_test_force_first_cap(uint64_t cap) { g_test_first_cap.store(cap, std::memory_order_relaxed); }
 
 FrameEncoder* alice_codec_encoder_create_ex(uint8_t quality, uint8_t wavelet_type) {
     clear_error();
@@ -890,12 +929,23 @@ AliceBatch* alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t f
     if (encode_work_alloc(b->enc, d, (int)n_chunks) != kOk || b->evs.init() != kOk) { delete b; return nullptr; }
     return b;
 }
-void alice_codec_batch_destroy(AliceBatch* b) { delete b; }
+void alice_codec_batch_destroy(AliceBatch* b) {
+    if (!b) return;
+    {
+        // the caller's streams may be gone by now; drain the device the batch lives on before its buffers return to the pool
+        DeviceScope ds(b->device);
+        if (ds.ok) (void)hipDeviceSynchronize();
+        b->enc_stream = b->dec_stream = nullptr;
+    }
+    delete b;
+}
 
 int alice_codec_batch_encode(AliceBatch* b, const void* d_rgb, void* hip_stream) {
     clear_error();
     if (!b || !d_rgb) return fail(kNullArgument, "null argument");
-    TRY(ensure_device());
+    DeviceScope ds(b->device);
+    if (!ds.ok) return tl_err;
+    tl_scope_stream = nullptr;   // batch buffers outlive the call; alice_codec_batch_destroy drains the device
     b->enc_stream = (hipStream_t)hip_stream;
     b->enc_timed = false;
     b->last_rgb = (const uint8_t*)d_rgb;
@@ -904,6 +954,9 @@ int alice_codec_batch_encode(AliceBatch* b, const void* d_rgb, void* hip_stream)
 int alice_codec_batch_encode_finish(AliceBatch* b, uint64_t* sizes) {
     clear_error();
     if (!b) return fail(kNullArgument, "null argument");
+    DeviceScope ds(b->device);
+    if (!ds.ok) return tl_err;
+    tl_scope_stream = nullptr;
     std::vector<RansResult> res;
     int rc = encode_collect(b->enc, b->enc_stream, res);
     if (rc == -1 && b->last_rgb) {  // capacity estimate exceeded (never observed): run again with the worst case
@@ -930,6 +983,8 @@ uint64_t alice_codec_batch_padded_pixels(const AliceBatch* b) { return b ? b->d.
 int alice_codec_batch_pack_alc(AliceBatch* b, const uint64_t* sizes, void* d_dst, uint64_t dst_capacity, void* hip_stream) {
     clear_error();
     if (!b || !sizes || !d_dst) return fail(kNullArgument, "null argument");
+    DeviceScope ds(b->device);
+    if (!ds.ok) return tl_err;
     uint64_t off = 0;
     for (uint32_t i = 0; i < b->n_chunks; ++i) {
         if (sizes[i] > b->enc.alc_stride || off + sizes[i] > dst_capacity) return fail(kInvalidBufferSize, "pack buffer too small");
@@ -943,7 +998,9 @@ int alice_codec_batch_pack_alc(AliceBatch* b, const uint64_t* sizes, void* d_dst
 int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stride, void* d_rgb_out, void* hip_stream) {
     clear_error();
     if (!b || !d_alc) return fail(kNullArgument, "null argument");
-    TRY(ensure_device());
+    DeviceScope ds(b->device);
+    if (!ds.ok) return tl_err;
+    tl_scope_stream = nullptr;
     hipStream_t st = (hipStream_t)hip_stream;
     b->dec_stream = st;
     b->dec_timed = false;
@@ -980,6 +1037,8 @@ const void* alice_codec_batch_rgb_ptr(const AliceBatch* b, uint32_t chunk) {
 int alice_codec_batch_decode_finish(AliceBatch* b) {
     clear_error();
     if (!b) return fail(kNullArgument, "null argument");
+    DeviceScope ds(b->device);
+    if (!ds.ok) return tl_err;
     TRY(decode_collect(b->dec, b->dec_stream));
     (void)hipEventElapsedTime(&b->stage_ms[4], b->evs.ev[5], b->evs.ev[6]);
     (void)hipEventElapsedTime(&b->stage_ms[5], b->evs.ev[6], b->evs.ev[7]);
@@ -1134,9 +1193,11 @@ int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t c
     HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(symbols, dout.p, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (res.flags & kRansInternal) return fail(kInternal, "decode table outside the packed range (freq > 4096 with live slots)");
+    note_decode_stats(res);
+    if (res.flags & kRansInternal) return fail(kInternal, "rANS decode kernel invariant violated");
     return kOk;
 }
+void alice_codec_test_last_decode_stats(uint32_t out[4]) { if (out) for (int i = 0; i < 4; ++i) out[i] = tl_dec_stats[i]; }
 
 // ssim / ms_ssim (src/ssim.rs:63-176).  Returns the value, or -1.0 with the thread's error set (the Result::Err cases).
 static int ssim_device(const uint8_t* d_a, const uint8_t* d_b, uint64_t w, uint64_t h, double* d_blocks, double* d_acc,
@@ -1506,6 +1567,7 @@ int alice_codec_dev_forward_symbols(const void* d_rgb, uint32_t width, uint32_t 
     if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count exceeds u32");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
+    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     EncodeWork w;
     w.d = d; w.n_chunks = 1;
     TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
@@ -1529,8 +1591,10 @@ int alice_codec_dev_inverse_symbols(const void* d_symbols, uint32_t width, uint3
     TRY(checked_pixel_count(width, height, frames, &n_pixels));
     if (n_pixels == 0) return fail(kInvalidDimensions, "invalid dimensions");
     const ChunkDims d = make_dims(width, height, frames);
+    if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count exceeds u32");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
+    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     DecodeWork w;
     w.d = d; w.n_chunks = 1;
     TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
@@ -1548,6 +1612,7 @@ int alice_codec_dev_histogram(const void* d_symbols, uint64_t n, void* d_hist, v
     if (!d_hist || (!d_symbols && n)) return fail(kNullArgument, "null argument");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
+    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), st));
     if (n) launch_histogram((const uint8_t*)d_symbols, n, (uint32_t*)d_hist, st);
     HIP_TRY(hipGetLastError());
@@ -1569,6 +1634,7 @@ int alice_codec_dev_rans_encode(const void* d_symbols, uint64_t n, const uint32_
     if (cap < 4 + 64 + 64) return fail(kInvalidBufferSize, "stream region too small");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
+    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     DevBuf dh, dt, dres;
     TRY(dh.alloc(256 * 4)); TRY(dt.alloc(sizeof(RansTable))); TRY(dres.alloc(sizeof(RansResult)));
     HIP_TRY(hipMemcpyAsync(dh.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
@@ -1593,6 +1659,7 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
     if (!n) return kOk;
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
+    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     DevBuf dh, dt, ddesc, dres;
     TRY(dh.alloc(256 * 4)); TRY(dt.alloc(sizeof(RansTable))); TRY(ddesc.alloc(sizeof(RansDecodeDesc))); TRY(dres.alloc(sizeof(RansResult)));
     HIP_TRY(hipMemcpyAsync(dh.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
@@ -1603,6 +1670,7 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
     RansResult res{};
     HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    note_decode_stats(res);
     if (res.flags & kRansInternal) return fail(kInternal, "rANS decode table invariant violated");
     return kOk;
 }

@@ -97,19 +97,20 @@ static_assert(sizeof(RansTable) % 32 == 0 && offsetof(RansTable, dec) % 32 == 0,
 
 struct ChunkDims {
     uint32_t w, h, f;     // as given
-    uint32_t pw, ph, pf;  // padded to even (f == 1 -> 2), reference src/pipeline.rs:437-439
+    uint64_t pw, ph, pf;  // padded to even (f == 1 -> 2), reference src/pipeline.rs:437-439 (usize there: 0xFFFFFFFF pads to 2^32)
     uint64_t n_pixels;    // w*h*f
-    uint64_t padded;      // pw*ph*pf
+    uint64_t padded;      // pw*ph*pf, saturated at 2^64 - 1 (callers reject anything above the header's u32 num_symbols)
 };
 
 inline ChunkDims make_dims(uint32_t w, uint32_t h, uint32_t f) {
     ChunkDims d{};
     d.w = w; d.h = h; d.f = f;
-    d.pw = w + (w & 1u);
-    d.ph = h + (h & 1u);
-    d.pf = (f == 1u) ? 2u : f + (f & 1u);
+    d.pw = (uint64_t)w + (w & 1u);
+    d.ph = (uint64_t)h + (h & 1u);
+    d.pf = (f == 1u) ? 2ull : (uint64_t)f + (f & 1u);
     d.n_pixels = (uint64_t)w * h * f;
-    d.padded = (uint64_t)d.pw * d.ph * d.pf;
+    const unsigned __int128 p = (unsigned __int128)d.pw * d.ph * d.pf;   // < 2^99
+    d.padded = p > (unsigned __int128)UINT64_MAX ? UINT64_MAX : (uint64_t)p;
     return d;
 }
 

@@ -18,7 +18,21 @@ struct RansResult {
     uint32_t cycles_k, ticks_k;
     uint32_t hw_id;           // HW_REG_HW_ID: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]
     uint32_t xcc_id;          // HW_REG_XCC_ID [3:0]
+    uint32_t paths;           // decode: which branches of the tile loop ran (kDecPath*), for the test-suite's coverage check
+    uint32_t pad_;
 };
+
+constexpr uint32_t kDecPathDry = 1u;          // stream exhausted: no-window tile
+constexpr uint32_t kDecPathWhole = 2u;        // fast tile on a window that lies wholly inside the stream
+constexpr uint32_t kDecPathSpecKept = 4u;     // fast tile on a zero-padded window, no padding consumed
+constexpr uint32_t kDecPathSpecDropped = 8u;  // ... padding consumed: result dropped, exact loop redid the tile
+constexpr uint32_t kDecPathPendingFed = 16u;  // renormalisation owed by an exact-loop symbol settled before a fast tile
+constexpr uint32_t kDecPathExact = 32u;       // exact scalar-lane loop
+constexpr uint32_t kDecPathStarved = 64u;     // exact loop stopped at the end of its window with bytes still owed
+constexpr uint32_t kDecPathTail = 128u;       // last tile of fewer than 4096 symbols
+constexpr uint32_t kDecPathUnaligned = 256u;  // output not dword aligned
+constexpr uint32_t kDecPathBelowL = 512u;     // fast tile refused: state below 2^23 with no renormalisation owed
+constexpr uint32_t kDecPathStillStarved = 1024u;  // fast tile refused: the owed renormalisation could not reach 2^23
 
 struct RansDecodeDesc {
     const uint8_t* in;        // channel stream

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
     bool pending = false;  // renormalisation owed by the previous symbol
     const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
     unsigned long long done = 0ull;
-    uint32_t n_fast = 0u, n_slow = 0u;
+    uint32_t n_fast = 0u, n_slow = 0u, paths = 0u;
 
     while (done < d.n) {
         const unsigned long long remain = d.n - done;
@@ -556,6 +556,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             x = xs;
             __syncthreads();
             const bool out_al = (((uintptr_t)(d.out + done)) & 3u) == 0u;
+            paths |= kDecPathDry | (out_al ? 0u : kDecPathUnaligned);
             for (int i = lane * 4; i < kDecTile; i += 256) {
                 const uint2 r4 = *(const uint2*)&rec[i];
                 const uint32_t packed = (uint32_t)c2s[r4.x & (kProbScale - 1u)] | ((uint32_t)c2s[(r4.x >> 16) & (kProbScale - 1u)] << 8) |
@@ -611,10 +612,10 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             unsigned long long ps = pos;
             int guard = 0;
             while (xs < kRansL && ps < len && guard < 8) { xs = (xs << 8) | (uint32_t)win[ps - wbase]; ps += 1ull; ++guard; }
-            if (xs < kRansL) fast = false;  // still starved: leave x/pos untouched for the exact loop
-            else { x = xs; pos = ps; pending = false; }
+            if (xs < kRansL) { fast = false; paths |= kDecPathStillStarved; }  // still starved: leave x/pos untouched for the exact loop
+            else { x = xs; pos = ps; pending = false; paths |= kDecPathPendingFed; }
         }
-        if (fast && x < kRansL) fast = false;  // only the very first symbol of a malformed stream
+        if (fast && x < kRansL) { fast = false; paths |= kDecPathBelowL; }  // only the very first symbol of a malformed stream
         if (fast) {
             uint32_t prel = (uint32_t)(pos - wbase);
             uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
@@ -628,6 +629,9 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
             if (pos > len) {  // uniform: padding was consumed
                 x = x_save; pos = pos_save; pending = pending_save;
                 fast = false;
+                paths |= kDecPathSpecDropped;
+            } else {
+                paths |= whole ? kDecPathWhole : kDecPathSpecKept;
             }
         }
         if (fast) {
@@ -640,13 +644,15 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
                 if (out_aligned) *(uint32_t*)(d.out + done + i) = packed;
                 else *(uint32_t*)(obuf + i) = packed;
             }
+            paths |= out_aligned ? 0u : kDecPathUnaligned;
             got = out_aligned ? 0u : (uint32_t)kDecTile;   // 0: nothing left in obuf to flush
             done += out_aligned ? (unsigned long long)kDecTile : 0ull;
             ++n_fast;
         } else {
             ++n_slow;
+            paths |= kDecPathExact | (want < (uint32_t)kDecTile ? kDecPathTail : 0u);
             // exact scalar-lane loop over what the window can feed
-            __shared__ uint32_t sh_state, sh_cnt;
+            __shared__ uint32_t sh_state, sh_cnt, sh_starved;
             __shared__ unsigned long long sh_pos;
             if (lane == 0) {
                 uint32_t j = 0u, xs = x;
@@ -671,10 +677,11 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
                     pend = true;
                     ++j;
                 }
-                sh_state = xs; sh_pos = ps; sh_cnt = j;
+                sh_state = xs; sh_pos = ps; sh_cnt = j; sh_starved = starved ? 1u : 0u;
             }
             __syncthreads();
             x = sh_state; pos = sh_pos; got = sh_cnt;
+            paths |= sh_starved ? kDecPathStarved : 0u;
             pending = true;
         }
         __syncthreads();
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         results[blockIdx.x].final_state = x;
         results[blockIdx.x].fast_tiles = n_fast;
         results[blockIdx.x].slow_tiles = n_slow;
+        results[blockIdx.x].paths = paths;
         results[blockIdx.x].cycles_k = (uint32_t)((clock64() - clk0) >> 10);
         results[blockIdx.x].ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
         results[blockIdx.x].hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);

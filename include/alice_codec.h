@@ -88,6 +88,13 @@ const char *alice_codec_last_error_message(void); /* thread-local, valid until t
 int alice_codec_device_count(void);
 int alice_codec_set_device(int device);           /* device used by this thread's later calls */
 void alice_codec_trim(void);                      /* release cached device memory */
+/* TEST ONLY: the next encodes size their stream regions with this capacity instead of the histogram-derived one
+ * (0 = off), so that the suite can drive the overflow-and-retry path.  Never needed by a caller. */
+void alice_codec_test_force_first_cap(uint64_t cap);
+/* TEST ONLY: the last alice_codec_rans_decode / alice_codec_dev_rans_decode of the calling thread: tiles taken by the fast
+ * path, tiles taken by the exact loop, the mask of tile-loop branches that ran (kDecPath* in csrc/kernels.h), stream
+ * bytes consumed. */
+void alice_codec_test_last_decode_stats(uint32_t out[4]);
 
 /* FrameEncoder::with_wavelet (src/pipeline.rs:356) */
 FrameEncoder *alice_codec_encoder_create_ex(uint8_t quality, uint8_t wavelet_type);

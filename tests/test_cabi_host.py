@@ -114,6 +114,46 @@ def test_validation_precedes_device_use(codec):
     assert e.value.kind == "InvalidBufferSize"
 
 
+def test_dimensions_of_2_pow_32_minus_1(codec):
+    """0xFFFFFFFF pads to 2^32 in the reference's usize arithmetic (src/pipeline.rs:437-440, 548-551), so the padded
+    pixel count can never equal a u32 num_symbols: decode answers InvalidBitstream (:566-571) and nothing may be
+    launched for such a shape.  A u32 padding would wrap to 0 and let a crafted header with num_symbols = 0 through."""
+    big = 0xFFFFFFFF
+    for w, h, f in ((big, 1, 1), (1, big, 1), (1, 1, big), (big, big, 1)):
+        hdr = bytearray(3138)
+        hdr[0:4] = b"ALCC"; hdr[4] = 1; hdr[5] = 0
+        hdr[6:10] = w.to_bytes(4, "little"); hdr[10:14] = h.to_bytes(4, "little"); hdr[14:18] = f.to_bytes(4, "little")
+        for c in range(3):
+            hdr[18 + 1040 * c + 4: 18 + 1040 * c + 8] = (1).to_bytes(4, "little")    # step
+            hdr[18 + 1040 * c + 8: 18 + 1040 * c + 12] = (1).to_bytes(4, "little")   # dead zone
+        chunk = codec.EncodedChunk.from_bytes(bytes(hdr))                              # the header itself is well formed
+        with pytest.raises(codec.CodecError) as e:
+            codec.FrameDecoder().decode(chunk)
+        assert e.value.kind == ("InvalidBitstream" if w * h * f < 2**64 else "DimensionOverflow"), (w, h, f)
+        with pytest.raises(codec.CodecError) as e:
+            codec.Batch(w, h, f, 1, 80)
+        assert e.value.kind == "DimensionOverflow"
+    lib = codec.load_library()
+    fake = C.c_void_p(4096)   # never dereferenced: the shape is refused before any device call
+    assert lib.alice_codec_dev_forward_symbols(fake, big, 1, 1, 0, 80, fake, fake, None) == 3
+    step = (C.c_int32 * 3)(1, 1, 1)
+    assert lib.alice_codec_dev_inverse_symbols(fake, big, 1, 1, 0, step, fake, None) == 3
+
+
+def test_quality_must_fit_u8(codec):
+    """quality is a u8 in the reference (src/pipeline.rs:347, src/bin/main.rs): 300 must not encode as 44."""
+    for bad in (256, 300, -1):
+        with pytest.raises(ValueError):
+            codec.FrameEncoder(bad)
+        with pytest.raises(ValueError):
+            codec.FrameEncoder.with_wavelet(bad, codec.WaveletType.Cdf97)
+    assert codec.FrameEncoder(255).quality == 255
+    from alice_codec_amd import cli
+    for bad in ("300", "-1"):
+        with pytest.raises(SystemExit):
+            cli.main(["encode", "in.rgb", "-o", "out.alc", "-W", "4", "-H", "4", "-q", bad])
+
+
 def test_no_cpu_fallback(codec):
     """Without a HIP device a compute call must fail loudly with DeviceError, never compute on the host."""
     if codec.device_count() > 0:

@@ -168,7 +168,7 @@ def test_decoder_follows_desynchronised_streams(gpu_codec, oracle_mod):
         assert np.array_equal(got, ref), trial
 
 
-def test_stream_capacity_overflow_is_retried(gpu_codec, oracle_mod, monkeypatch):
+def test_stream_capacity_overflow_is_retried(gpu_codec, oracle_mod):
     """Stream regions are sized from the histograms; if a chain ever outgrew its region the kernels must not
     touch memory outside it and the host must encode again with the worst-case capacity.  The test hook shrinks
     the first capacity to 4352 bytes so that path runs."""
@@ -176,9 +176,12 @@ def test_stream_capacity_overflow_is_retried(gpu_codec, oracle_mod, monkeypatch)
     rgb = np.random.default_rng(21).integers(0, 256, w * h * f * 3, dtype=np.uint8)
     ref = oracle_mod.encode(rgb, w, h, f, 90, 1)
     assert len(ref) > 3138 + 3 * 4352
-    monkeypatch.setenv("ALICE_CODEC_TEST_TINY_CAP", "1")
-    got = gpu_codec.FrameEncoder.with_wavelet(90, gpu_codec.WaveletType.Cdf97).encode(rgb, w, h, f).to_bytes()
-    monkeypatch.delenv("ALICE_CODEC_TEST_TINY_CAP")
+    lib = gpu_codec.load_library()
+    lib.alice_codec_test_force_first_cap(4352)
+    try:
+        got = gpu_codec.FrameEncoder.with_wavelet(90, gpu_codec.WaveletType.Cdf97).encode(rgb, w, h, f).to_bytes()
+    finally:
+        lib.alice_codec_test_force_first_cap(0)
     assert got == ref
 
 
