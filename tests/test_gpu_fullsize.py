@@ -1,0 +1,119 @@
+"""BASELINE.json configs[3] and configs[4] at their stated sizes, in the driver-run suite.
+
+configs[3]  3840x2160x64 CDF 9/7 q=90: one chunk through the drop-in encode/decode (the 8-chunks-on-8-GPUs part of the
+            config is chunk-parallel: every GPU runs exactly this; the gather is covered by tests/test_distributed_cpu.py).
+configs[4]  7680x4320 CDF 9/7 q=75: (a) the row-slab sharded path (alice-codec_amd/slab.py) with 4 ranks sharing the
+            test GPU at the full 8K frame size, 8 frames, against the oracle; (b) a single-GPU encode of the full
+            7680x4320x64 chunk (2,123,366,400 symbols per chain, just under the header's u32) checked through
+            size-independent properties -- the oracle needs about six minutes for this size, which the suite's
+            budget does not have (the builder-side run of it is profiles/r01_slab_check_8k64_world4.jsonl).
+Inputs are generated on the GPU and copied to the host, so that oracle and GPU path read the same bytes."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def smooth_on_gpu(w, h, f, seed):
+    """S-smooth as a uint8 CUDA tensor [f, h, w, 3]."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty((f, h, w, 3), dtype=torch.uint8, device=dev)
+    y = torch.arange(h, device=dev, dtype=torch.float32).view(h, 1, 1)
+    x = torch.arange(w, device=dev, dtype=torch.float32).view(1, w, 1)
+    s = torch.tensor([23.0, 31.0, 17.0], device=dev).view(1, 1, 3)
+    ph = torch.tensor([0.0, 1.0, 2.0], device=dev).view(1, 1, 3)
+    for t in range(f):
+        base = 128 + 90 * torch.sin((x + 2 * t) / s + ph) * torch.cos((y - t) / (0.7 * s))
+        out[t] = (base + torch.randint(-4, 5, (h, w, 3), device=dev, generator=g)).round().clamp(0, 255).to(torch.uint8)
+    return out
+
+
+def test_config3_4k64_cdf97_q90_single_chunk(gpu_codec, oracle_mod):
+    w, h, f, q, k = 3840, 2160, 64, 90, 1
+    rgb = smooth_on_gpu(w, h, f, 4090).cpu().numpy().reshape(-1)
+    chunk = gpu_codec.FrameEncoder.with_wavelet(q, gpu_codec.WaveletType(k)).encode(rgb, w, h, f)
+    got = chunk.to_bytes()
+    # the oracle with the three channels on three threads: the same bytes as its single-threaded run (checked on every
+    # bench run and in test_oracle_* on small inputs), a third of the wait
+    ref = oracle_mod.encode(rgb, w, h, f, q, k, three_threads=True)
+    assert len(got) == len(ref)
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(ref).hexdigest()
+    dec = gpu_codec.FrameDecoder().decode(chunk)
+    want = oracle_mod.decode(ref, three_threads=True)
+    assert dec.size == rgb.size and np.array_equal(dec, want)
+
+
+def test_config4_8k_row_slabs_world4_vs_oracle():
+    """7680x4320 frames, 8 of them, CDF 9/7 q=75, 4 ranks sharing the GPU: 8K-wide tiles and grids, 1080-row slabs with
+    4-row halos, histogram all-reduce, symbol rows to the three chain ranks; the sharded .alc and decode against the
+    single-GPU path and the oracle."""
+    tool = os.path.join(ROOT, "tests", "tools", "slab_fullsize_check.py")
+    p = subprocess.run([sys.executable, tool, "7680", "4320", "8", "75", "1", "4", "--oracle3"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["shape"] == [7680, 4320, 8] and res["world"] == 4
+    for key in ("alc_equal_single_gpu", "decode_equal_single_gpu", "alc_equal_oracle", "decode_equal_oracle"):
+        assert res[key] is True, (key, res)
+
+
+def test_config4_8k64_single_gpu_encode_properties(gpu_codec):
+    """The full 7680x4320x64 chunk on one GPU, device to device (alice_codec_batch_*): 6.37 GB of RGB, 2.12 G symbols per
+    chain.  Checked: header fields, each histogram sums to num_symbols, the three stream lengths add up to the chunk
+    size, every stream starts with a normalised rANS state (RansEncoder::finish leaves the final state big-endian in
+    front: src/rans.rs:298-308; states live in [2^23, 2^31)), and the histograms equal an independent count of the
+    symbols the stage call alice_codec_dev_forward_symbols produces for the same input."""
+    import torch
+    w, h, f, q, k = 7680, 4320, 64, 75, 1
+    padded = w * h * f
+    assert padded == 2_123_366_400 < 2**32
+    rgb = smooth_on_gpu(w, h, f, 8192)
+    bt = gpu_codec.Batch(w, h, f, 1, q, gpu_codec.WaveletType(k))
+    st = torch.cuda.current_stream().cuda_stream
+    bt.encode(rgb.data_ptr(), st)
+    sizes = bt.encode_finish()
+    n = int(sizes[0])
+    from alice_codec_amd import multi
+    alc = multi.DeviceView(bt.alc_ptr(0), n).tensor(rgb.device)
+    hdr = alc[:3138].cpu().numpy().tobytes()
+    assert hdr[:6] == b"ALCC\x01\x01"
+    assert [int.from_bytes(hdr[6 + 4 * i: 10 + 4 * i], "little") for i in range(3)] == [w, h, f]
+    lens, hists = [], []
+    for c in range(3):
+        base = 18 + 1040 * c
+        lens.append(int.from_bytes(hdr[base:base + 4], "little"))
+        assert int.from_bytes(hdr[base + 4:base + 8], "little") == 17          # q=75 -> step 17 (src/pipeline.rs:456-457)
+        assert int.from_bytes(hdr[base + 8:base + 12], "little") == 17
+        assert int.from_bytes(hdr[base + 12:base + 16], "little") == padded
+        hist = np.frombuffer(hdr[base + 16:base + 1040], "<u4").astype(np.uint64)
+        assert int(hist.sum()) == padded
+        hists.append(hist)
+    assert 3138 + sum(lens) == n
+    off = 3138
+    for c in range(3):
+        assert lens[c] >= 4
+        state = int.from_bytes(alc[off:off + 4].cpu().numpy().tobytes(), "big")
+        assert 2**23 <= state < 2**31, (c, hex(state))
+        off += lens[c]
+    del bt, alc
+    gpu_codec.load_library().alice_codec_trim()
+    torch.cuda.empty_cache()
+    sym = torch.empty(3 * padded, dtype=torch.uint8, device=rgb.device)
+    rc = gpu_codec.load_library().alice_codec_dev_forward_symbols(rgb.data_ptr(), w, h, f, k, q, sym.data_ptr(), None, st)
+    assert rc == 0
+    for c in range(3):
+        counts = torch.zeros(256, dtype=torch.int64, device=rgb.device)
+        part = sym[c * padded:(c + 1) * padded]
+        for a in range(0, padded, 1 << 28):   # bincount in pieces (it widens its input to int64)
+            counts += torch.bincount(part[a:a + (1 << 28)].to(torch.int64), minlength=256)
+        assert np.array_equal(counts.cpu().numpy().astype(np.uint64), hists[c]), c

@@ -559,7 +559,7 @@ def test_full_size_1080p64_cdf97_q80(gpu_codec, oracle_mod):   # BASELINE.json c
 
 
 def test_full_size_1080p64_cdf53_q80(gpu_codec, oracle_mod):   # BASELINE.json configs[1]
-    _full_size(gpu_codec, oracle_mod, 0, 80, False)
+    _full_size(gpu_codec, oracle_mod, 0, 80, True)
 
 
 def test_4k_frames_cdf97_q90(gpu_codec, oracle_mod):

@@ -2,7 +2,9 @@
 `world` ranks share cuda:0 and exchange over gloo.  Compares the sharded `.alc` with the single-GPU encode of the
 whole chunk (and, with --oracle, with the CPU oracle), and the sharded decode with the single-GPU decode.
 
-  python tests/tools/slab_fullsize_check.py W H F QUALITY WAVELET WORLD [--oracle]
+  python tests/tools/slab_fullsize_check.py W H F QUALITY WAVELET WORLD [--oracle | --oracle3]
+
+--oracle3 runs the oracle with Y, Co, Cg on three threads (the same bytes, a third of the wait).
 
 Prints one JSON line per phase (progress) and a final summary on rank 0."""
 import hashlib
@@ -96,11 +98,11 @@ def worker(rank, world, port, args, use_oracle):
             import oracle as o
             o.build()
             t0 = time.time()
-            ref = np.frombuffer(o.encode(full, w, h, f, q, wavelet), np.uint8)
+            ref = np.frombuffer(o.encode(full, w, h, f, q, wavelet, three_threads=use_oracle == 3), np.uint8)
             say(phase="oracle encode (1 CPU thread)", seconds=round(time.time() - t0, 2))
             res["alc_equal_oracle"] = bool(ref.size == got.size and np.array_equal(ref, got))
             t0 = time.time()
-            rdec = o.decode(ref)
+            rdec = o.decode(ref, three_threads=use_oracle == 3)
             say(phase="oracle decode (1 CPU thread)", seconds=round(time.time() - t0, 2))
             res["decode_equal_oracle"] = bool(np.array_equal(rdec, dec))
         res.update(shape=[w, h, f], quality=q, wavelet=wavelet, world=world, alc_bytes=int(got.size),
@@ -117,7 +119,8 @@ if __name__ == "__main__":
     w, h, f, q, wavelet, world = (int(v) for v in a[:6])
     ctx = mp.get_context("spawn")
     port = 34000 + os.getpid() % 2000
-    procs = [ctx.Process(target=worker, args=(r, world, port, (w, h, f, q, wavelet), "--oracle" in sys.argv)) for r in range(world)]
+    use_oracle = 3 if "--oracle3" in sys.argv else (1 if "--oracle" in sys.argv else 0)
+    procs = [ctx.Process(target=worker, args=(r, world, port, (w, h, f, q, wavelet), use_oracle)) for r in range(world)]
     [p.start() for p in procs]
     [p.join() for p in procs]
     sys.exit(max(abs(p.exitcode or 0) for p in procs))
