@@ -303,7 +303,7 @@ inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 // dequantised sample is at most 128 * |step|; each lifting step adds at most (2 * other * |c| + 4096) / 8192 + 1.
 // fast: 32-bit (24 x 24-bit) products are exact everywhere.  mid16: additionally every value after the
 // temporal pass fits i16, so the intermediate can be stored in 16 bits.
-struct InverseBounds { bool fast; bool mid16; };
+struct InverseBounds { bool fast; bool mid16; bool lds16; };
 InverseBounds inverse_bounds(int wavelet, const int32_t step[3]) {
     const LiftSteps ls = lift_steps(wavelet);
     long double worst = 0;
@@ -311,7 +311,7 @@ InverseBounds inverse_bounds(int wavelet, const int32_t step[3]) {
         long double a = 128.0L * fabsl((long double)step[c]);
         if (a > worst) worst = a;
     }
-    InverseBounds r{true, false};
+    InverseBounds r{true, false, false};
     long double m = worst;  // bound on every sample
     for (int pass = 0; pass < 3; ++pass) {
         long double me = m, mo = m;
@@ -326,6 +326,7 @@ InverseBounds inverse_bounds(int wavelet, const int32_t step[3]) {
         }
         m = me > mo ? me : mo;
         if (pass == 0) r.mid16 = m <= 32767.0L;
+        if (pass == 1) r.lds16 = r.mid16 && m <= 32767.0L;
     }
     return r;
 }
@@ -571,7 +572,7 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
         const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
         const uint8_t* sym = w.sym_ptr + (size_t)b * 3 * d.padded;
         uint8_t* rgb = d_rgb_out + (size_t)b * (rgb_stride ? rgb_stride : d.n_pixels * 3);
-        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, w.mid_ptr, rgb, st))
+        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.mid_ptr, rgb, st))
             TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, rgb, st));
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[7], st));
@@ -1600,7 +1601,7 @@ int alice_codec_dev_inverse_symbols(const void* d_symbols, uint32_t width, uint3
     TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
     w.mid_ptr = w.mid.as<int32_t>();
     const InverseBounds ib = inverse_bounds(wavelet_type, step);
-    if (!launch_inverse_transform((const uint8_t*)d_symbols, d, wavelet_type, step, !ib.fast, ib.fast && ib.mid16, w.mid_ptr, (uint8_t*)d_rgb, st))
+    if (!launch_inverse_transform((const uint8_t*)d_symbols, d, wavelet_type, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.mid_ptr, (uint8_t*)d_rgb, st))
         TRY(inverse_generic((const uint8_t*)d_symbols, d, wavelet_type, step, w, (uint8_t*)d_rgb, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));

@@ -70,9 +70,10 @@ void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, in
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
                               int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st);
 // steps/dead zones per channel come from the chunk header.  exact = 64-bit lifting products.
-// mid16 = the intermediate after the temporal pass provably fits i16 (halves its traffic).
+// mid16 = the intermediate after the temporal pass provably fits i16 (halves its traffic); lds16 = so does
+// everything after the column pass (halves the tile kernel's LDS footprint).
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
-                              bool exact, bool mid16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st);
+                              bool exact, bool mid16, bool lds16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st);
 
 // ---- generic.hip (stage-level API on arbitrary i32 data; exact reference arithmetic) ----
 // 1-D transform of n_lines lines: element k of line (a, b) is at data[a*stride_a + b*stride_b + k*stride_k],

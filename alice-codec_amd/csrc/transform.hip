@@ -573,23 +573,43 @@ __global__ __launch_bounds__(256) void inv_t_kernel(const uint8_t* __restrict__ 
 // K4: inverse spatial transform of one frame tile + colour
 // ------------------------------------------------------------------------------------------------
 constexpr int I_TW = 96, I_TH = 32, I_SEG = 8, I_NSEG = 12, I_THREADS = 384;
+constexpr int I_HO = 52;    // LDS column of the first odd (high-band) sample of a row: the two halves sit at 0 and 52
+constexpr int I_LW = 108;   // LDS row pitch in dwords: a multiple of 4, so that every 8-sample run stage B reads is two
+                            // aligned ds_read_b128 (conflict-free: 16 lanes x 4 dwords span the 64 banks), and k * 108 + x
+                            // keeps the column-major stores of stage A on 32 different banks
 
-template <int NS, bool EDGE, bool EXACT, typename MidT>
+// LDS16: the host proved that every value after the inverse column lifting fits i16 (InverseBounds::lds16): two tile rows
+// share a dword, which halves the tile (25 KB instead of 50 KB: five workgroups per CU instead of three).
+template <int NS, bool EDGE, bool EXACT, typename MidT, bool LDS16>
 __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restrict__ mid, uint8_t* __restrict__ rgb,
-                                                           ChunkDims d, Coeffs cf, int aligned) {
+                                                           ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
     constexpr int H = NS;
     constexpr int ER = I_TH + 2 * H;        // rows incl. halo
     constexpr int EC = I_TW + 2 * H;        // columns incl. halo (104 / 100)
     constexpr int ECh = EC / 2;
-    constexpr int LW = 105;                 // LDS row pitch (odd: stage-B reads stay at <= 2-way conflicts)
+    constexpr int LR = LDS16 ? ER / 2 : ER; // LDS rows per channel
     constexpr int NL = I_SEG + 2 * H;       // samples lifted per segment
-    __shared__ int lds[3 * ER * LW];
+    __shared__ __attribute__((aligned(16))) int lds[3 * LR * I_LW];
     const int tid = threadIdx.x;
-    const unsigned ntx = (d.w + I_TW - 1) / I_TW, nty = (d.h + I_TH - 1) / I_TH;
-    const unsigned lb = xcd_logical_block(ntx * nty * d.f);
-    if (lb == 0xFFFFFFFFu) return;
-    const int t = (int)(lb / (ntx * nty));
-    const int gx0 = (int)((lb % (ntx * nty)) % ntx) * I_TW, gy0 = (int)((lb % (ntx * nty)) / ntx) * I_TH;
+    // interior launch: a rectangle of tiles whose halo lies inside the frame (no mirroring, no clamping, no bounds
+    // tests); border launch: one linear sequence over the four strips around it
+    int bx, by, t;
+    {
+        const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
+        const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
+        const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
+        const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
+        const unsigned lb = xcd_logical_block(per_frame * d.f);
+        if (lb == 0xFFFFFFFFu) return;
+        t = (int)(lb / per_frame);
+        int i = (int)(lb % per_frame);
+        if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
+        else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
+        else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
+        else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
+        else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
+    }
+    const int gx0 = bx * I_TW, gy0 = by * I_TH;
     const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
     const int gpx0 = (gx0 - H) / 2;  // first column pair of the extended tile (may be negative)
 
@@ -604,16 +624,29 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
             int v[ER];
             const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + (px >> 1);
             const int gy_s = gy0 - H;
+            if (EDGE) {
 #pragma unroll
-            for (int k = 0; k < ER; ++k) {
-                const int gy = EDGE ? reflect_idx(gy_s + k, ph) : gy_s + k;
-                const int yy = (gy & 1) * hh + (gy >> 1);
-                v[k] = (int)src[(size_t)yy * pw];
+                for (int k = 0; k < ER; ++k) {
+                    const int gy = reflect_idx(gy_s + k, ph);
+                    const int yy = (gy & 1) * hh + (gy >> 1);
+                    v[k] = (int)src[(size_t)yy * pw];
+                }
+            } else {
+                // gy_s is even: even rows of the tile are low-band rows gy_s / 2 + m, odd rows high-band rows hh + gy_s / 2 + m
+                const MidT* lo = src + (size_t)(gy_s >> 1) * pw;
+                const MidT* hi = lo + (size_t)hh * pw;
+#pragma unroll
+                for (int m = 0; m < ER / 2; ++m) { v[2 * m] = (int)lo[(size_t)m * pw]; v[2 * m + 1] = (int)hi[(size_t)m * pw]; }
             }
             lift_regs<ER, NS, EXACT, true>(v, cf);
-            int* L = lds + (ch * ER) * LW + xq;
+            int* L = lds + (ch * LR) * I_LW + par * I_HO + j;
+            if (LDS16) {
 #pragma unroll
-            for (int k = 0; k < ER; ++k) L[k * LW] = v[k];
+                for (int m = 0; m < ER / 2; ++m) L[m * I_LW] = (v[2 * m] & 0xFFFF) | (v[2 * m + 1] << 16);
+            } else {
+#pragma unroll
+                for (int k = 0; k < ER; ++k) L[k * I_LW] = v[k];
+            }
         }
     }
     __syncthreads();
@@ -623,36 +656,46 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
         const int r = tid / I_NSEG, s = tid % I_NSEG;  // 384 = 32 * 12
         const int gy = gy0 + r;
         const int gxs = gx0 + s * I_SEG;               // first interior pixel of the segment
-        if (gy < (int)d.h && gxs < (int)d.w) {
+        if (!EDGE || (gy < (int)d.h && gxs < (int)d.w)) {
             int y[NL], co[NL], cg[NL];
-            const int lx0 = s * I_SEG;                 // offset of sample 0 inside the extended tile (even)
-            const int* L0 = lds + (0 * ER + r + H) * LW;
-            const int* L1 = lds + (1 * ER + r + H) * LW;
-            const int* L2 = lds + (2 * ER + r + H) * LW;
+            // sample k of the segment is extended-tile column s*8 + k: even k in the low half at dword s*4 + k/2,
+            // odd k in the high half at I_HO + s*4 + k/2
+            const int k = r + H;
+            const int lrow = LDS16 ? (k >> 1) : k;
+            const bool upper = LDS16 && (k & 1);
+            auto fetch = [&](int ch, int (&dst)[NL]) {
+                const int* Lc = lds + (ch * LR + lrow) * I_LW + s * 4;
 #pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int lx = lx0 + k;
-                const int q = (lx & 1) * ECh + (lx >> 1);
-                y[k] = L0[q]; co[k] = L1[q]; cg[k] = L2[q];
-            }
+                for (int half = 0; half < 2; ++half) {
+                    const int4 a = *(const int4*)(Lc + half * I_HO);
+                    const int4 b = *(const int4*)(Lc + half * I_HO + 4);
+                    const int w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int q = 0; q < NL / 2; ++q) {
+                        const int w = w8[q];
+                        dst[2 * q + half] = LDS16 ? (upper ? (w >> 16) : (int)(short)w) : w;
+                    }
+                }
+            };
+            fetch(0, y); fetch(1, co); fetch(2, cg);
             lift_regs<NL, NS, EXACT, true>(y, cf);
             lift_regs<NL, NS, EXACT, true>(co, cf);
             lift_regs<NL, NS, EXACT, true>(cg, cf);
             uint8_t out[I_SEG * 3];
 #pragma unroll
-            for (int k = 0; k < I_SEG; ++k) {
+            for (int kk = 0; kk < I_SEG; ++kk) {
                 // `as i16` (src/pipeline.rs:608) then wrapping i16 arithmetic (src/color.rs:266-273)
-                const short yv = (short)y[H + k], c_o = (short)co[H + k], c_g = (short)cg[H + k];
+                const short yv = (short)y[H + kk], c_o = (short)co[H + kk], c_g = (short)cg[H + kk];
                 const short tt = (short)(yv - (short)(c_g >> 1));
                 const short g = (short)(c_g + tt);
                 const short b = (short)(tt - (short)(c_o >> 1));
                 const short rr = (short)(c_o + b);
-                out[3 * k] = (uint8_t)min(max((int)rr, 0), 255);
-                out[3 * k + 1] = (uint8_t)min(max((int)g, 0), 255);
-                out[3 * k + 2] = (uint8_t)min(max((int)b, 0), 255);
+                out[3 * kk] = (uint8_t)min(max((int)rr, 0), 255);
+                out[3 * kk + 1] = (uint8_t)min(max((int)g, 0), 255);
+                out[3 * kk + 2] = (uint8_t)min(max((int)b, 0), 255);
             }
             uint8_t* p = rgb + (((size_t)t * d.h + gy) * d.w + gxs) * 3;
-            if (aligned && gxs + I_SEG <= (int)d.w) {
+            if (aligned && (!EDGE || gxs + I_SEG <= (int)d.w)) {
                 uint32_t* p4 = (uint32_t*)p;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
@@ -660,8 +703,8 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
                             ((uint32_t)out[4 * i + 3] << 24);
             } else {
 #pragma unroll
-                for (int k = 0; k < I_SEG; ++k)
-                    if (gxs + k < (int)d.w) { p[3 * k] = out[3 * k]; p[3 * k + 1] = out[3 * k + 1]; p[3 * k + 2] = out[3 * k + 2]; }
+                for (int kk = 0; kk < I_SEG; ++kk)
+                    if (gxs + kk < (int)d.w) { p[3 * kk] = out[3 * kk]; p[3 * kk + 1] = out[3 * kk + 1]; p[3 * kk + 2] = out[3 * kk + 2]; }
             }
         }
     }
@@ -730,7 +773,7 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
     return true;
 }
 
-template <int NS, bool EXACT, typename MidT>
+template <int NS, bool EXACT, typename MidT, bool LDS16>
 static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkDims& d, Coeffs cf, const int32_t step[3],
                        hipStream_t st) {
     const size_t plane = (size_t)d.pw * d.ph;
@@ -738,27 +781,42 @@ static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkD
     hipLaunchKernelGGL((inv_t_kernel<NS, EXACT, MidT>), gt, dim3(256), 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
     const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + I_TH - 1) / I_TH;
     const int aligned = (d.w % 4 == 0) && ((((uintptr_t)rgb) & 3u) == 0u);
-    dim3 grid(xcd_grid((unsigned long long)nx * ny * d.f));
-    // the inverse tiles are few enough per frame that one EDGE=true instance serves all of them
-    hipLaunchKernelGGL((inv_xy_kernel<NS, true, EXACT, MidT>), grid, dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned);
+    // a tile is interior when the range it reads, [gx0 - 4, gx0 + 96 + 4) x [gy0 - 4, gy0 + 32 + 4), lies inside w x h
+    // (then inside the padded frame too, and every pixel it writes exists)
+    auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * I_TW + I_TW + 4) <= d.w; };
+    auto interior_y = [&](unsigned by) { return by >= 1 && (by * I_TH + I_TH + 4) <= d.h; };
+    unsigned ix1 = 1, iy1 = 1;
+    while (ix1 < nx && interior_x(ix1)) ++ix1;
+    while (iy1 < ny && interior_y(iy1)) ++iy1;
+    const bool has_interior = ix1 > 1 && iy1 > 1;
+    TileMap tm{(int)nx, (int)ny, 0, 0, 0, 0};
+    if (has_interior) { tm.ix0 = 1; tm.ix1 = (int)ix1; tm.iy0 = 1; tm.iy1 = (int)iy1; }
+    else { tm.iy0 = (int)ny; tm.iy1 = (int)ny; }  // everything is "top strip"
+    const unsigned long long n_in = has_interior ? (unsigned long long)(ix1 - 1) * (iy1 - 1) : 0ull;
+    const unsigned long long n_edge = (unsigned long long)nx * ny - n_in;
+    if (n_in) hipLaunchKernelGGL((inv_xy_kernel<NS, false, EXACT, MidT, LDS16>), dim3(xcd_grid(n_in * d.f)), dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
+    if (n_edge) hipLaunchKernelGGL((inv_xy_kernel<NS, true, EXACT, MidT, LDS16>), dim3(xcd_grid(n_edge * d.f)), dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
 }
 
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
-                              bool exact, bool mid16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
+                              bool exact, bool mid16, bool lds16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
     const LiftSteps ls = lift_steps(wavelet);
     const Coeffs cf = to_coeffs(ls);
     if ((unsigned long long)d.pw * d.ph > (1ull << 30)) return false;   // 32-bit byte offsets inside one frame
     if (d.pw < 6 || d.ph < 6) return false;                             // reflect_idx: one reflection must cover the halo
     if ((unsigned long long)((d.w + I_TW - 1) / I_TW) * ((d.h + I_TH - 1) / I_TH) * d.f > 0x7FFFFFF0ull) return false;
-    // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too)
+    // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too);
+    // lds16: also after the inverse column pass
     if (ls.n == 4) {
-        if (exact) inv_launch<4, true, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
-        else if (mid16) inv_launch<4, false, int16_t>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
-        else inv_launch<4, false, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        if (exact) inv_launch<4, true, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        else if (mid16 && lds16) inv_launch<4, false, int16_t, true>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
+        else if (mid16) inv_launch<4, false, int16_t, false>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
+        else inv_launch<4, false, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
     } else {
-        if (exact) inv_launch<2, true, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
-        else if (mid16) inv_launch<2, false, int16_t>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
-        else inv_launch<2, false, int32_t>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        if (exact) inv_launch<2, true, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
+        else if (mid16 && lds16) inv_launch<2, false, int16_t, true>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
+        else if (mid16) inv_launch<2, false, int16_t, false>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
+        else inv_launch<2, false, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
     }
     return true;
 }
