@@ -177,6 +177,8 @@ def load_library() -> C.CDLL:
         "alice_codec_ycocg_r_to_rgb": (C.c_int, [_i16p, _i16p, _i16p, C.c_uint64, _u8p, C.c_uint64]),
         "alice_codec_dev_forward_symbols": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, vp, vp, vp]),
         "alice_codec_dev_inverse_symbols": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, _i32p, vp, vp]),
+        "alice_codec_dev_wavelet3d_forward": (C.c_int, [C.c_uint8, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
+        "alice_codec_dev_wavelet3d_inverse": (C.c_int, [C.c_uint8, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
         "alice_codec_dev_histogram": (C.c_int, [vp, C.c_uint64, vp, vp]),
         "alice_codec_rans_stream_bound": (C.c_uint64, [_u32p, C.c_uint64]),
         "alice_codec_dev_rans_encode": (C.c_int, [vp, C.c_uint64, _u32p, vp, C.c_uint64, _u64p, _u64p, vp]),

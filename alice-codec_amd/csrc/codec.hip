@@ -705,6 +705,22 @@ int staged(const Tin* in, uint64_t n_in, Tout* out, uint64_t n_out, Fn fn) {
     return kOk;
 }
 
+// Wavelet1D / 2D / 3D of a device-resident volume, result in `v` (tmp: same size).  Volumes the tile kernels cover run
+// their exact instances (two passes over the data); the rest -- odd lengths, tiny sizes, 1-D signals -- runs the
+// per-axis kernels of generic.hip.
+void wavelet_on_device(int kind, int32_t* v, int32_t* tmp, uint64_t W, uint64_t H, uint64_t D, int ndim, bool inverse, hipStream_t st) {
+    if (stage_tiles_eligible(W, H, D, ndim)) { launch_stage_wavelet(v, tmp, W, H, D, ndim, kind, inverse, st); return; }
+    if (!inverse) {
+        launch_wavelet_axis(v, tmp, W, 1, D * H, W, 1, 0, kind, false, st);
+        if (ndim >= 2) launch_wavelet_axis(v, tmp, H, W, D, W * H, W, 1, kind, false, st);
+        if (ndim >= 3) launch_wavelet_axis(v, tmp, D, W * H, 1, 0, W * H, 1, kind, false, st);
+    } else {
+        if (ndim >= 3) launch_wavelet_axis(v, tmp, D, W * H, 1, 0, W * H, 1, kind, true, st);
+        if (ndim >= 2) launch_wavelet_axis(v, tmp, H, W, D, W * H, W, 1, kind, true, st);
+        launch_wavelet_axis(v, tmp, W, 1, D * H, W, 1, 0, kind, true, st);
+    }
+}
+
 int wavelet_nd(int kind, int32_t* data, uint64_t W, uint64_t H, uint64_t D, int ndim, bool inverse) {
     if (!data) return fail(kNullArgument, "null data");
     if (kind < 0 || kind > 2) return fail(kInvalidBitstream, "unknown wavelet type");
@@ -718,17 +734,7 @@ int wavelet_nd(int kind, int32_t* data, uint64_t W, uint64_t H, uint64_t D, int 
     TRY(a.alloc(n * 4));
     TRY(t.alloc(n * 4));
     HIP_TRY(hipMemcpyAsync(a.p, data, n * 4, hipMemcpyHostToDevice, st));
-    int32_t* v = a.as<int32_t>();
-    int32_t* tmp = t.as<int32_t>();
-    if (!inverse) {
-        launch_wavelet_axis(v, tmp, W, 1, D * H, W, 1, 0, kind, false, st);
-        if (ndim >= 2) launch_wavelet_axis(v, tmp, H, W, D, W * H, W, 1, kind, false, st);
-        if (ndim >= 3) launch_wavelet_axis(v, tmp, D, W * H, 1, 0, W * H, 1, kind, false, st);
-    } else {
-        if (ndim >= 3) launch_wavelet_axis(v, tmp, D, W * H, 1, 0, W * H, 1, kind, true, st);
-        if (ndim >= 2) launch_wavelet_axis(v, tmp, H, W, D, W * H, W, 1, kind, true, st);
-        launch_wavelet_axis(v, tmp, W, 1, D * H, W, 1, 0, kind, true, st);
-    }
+    wavelet_on_device(kind, a.as<int32_t>(), t.as<int32_t>(), W, H, D, ndim, inverse, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(data, a.p, n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1606,6 +1612,27 @@ int alice_codec_dev_inverse_symbols(const void* d_symbols, uint32_t width, uint3
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     return kOk;
+}
+
+static int dev_wavelet3d(uint8_t k, void* d_volume, void* d_tmp, uint64_t w, uint64_t h, uint64_t d, bool inverse, void* hip_stream) {
+    clear_error();
+    if (!d_volume || !d_tmp) return fail(kNullArgument, "null argument");
+    if (k > 2) return fail(kInvalidBitstream, "unknown wavelet type");
+    unsigned __int128 tot = (unsigned __int128)w * h * d;
+    if (tot > ((unsigned __int128)1 << 40)) return fail(kDimensionOverflow, "volume too large");
+    if (tot == 0) return kOk;
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    wavelet_on_device(k, (int32_t*)d_volume, (int32_t*)d_tmp, w, h, d, 3, inverse, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return kOk;
+}
+int alice_codec_dev_wavelet3d_forward(uint8_t k, void* d_volume, void* d_tmp, uint64_t w, uint64_t h, uint64_t d, void* hip_stream) {
+    return dev_wavelet3d(k, d_volume, d_tmp, w, h, d, false, hip_stream);
+}
+int alice_codec_dev_wavelet3d_inverse(uint8_t k, void* d_volume, void* d_tmp, uint64_t w, uint64_t h, uint64_t d, void* hip_stream) {
+    return dev_wavelet3d(k, d_volume, d_tmp, w, h, d, true, hip_stream);
 }
 
 int alice_codec_dev_histogram(const void* d_symbols, uint64_t n, void* d_hist, void* hip_stream) {

@@ -75,6 +75,13 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
                               bool exact, bool mid16, bool lds16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st);
 
+// ---- transform.hip, stage level: Wavelet2D / Wavelet3D of caller-shaped i32 data on the tile kernels' exact instances ----
+// eligible: even width and height >= 6, even depth (or depth 1); otherwise the caller uses launch_wavelet_axis.
+bool stage_tiles_eligible(uint64_t w, uint64_t h, uint64_t depth, int ndim);
+// in place for the caller (result in d_data); d_tmp: same size.  ndim 2: `depth` independent planes.
+void launch_stage_wavelet(int32_t* d_data, int32_t* d_tmp, uint64_t w, uint64_t h, uint64_t depth, int ndim, int wavelet,
+                          bool inverse, hipStream_t st);
+
 // ---- generic.hip (stage-level API on arbitrary i32 data; exact reference arithmetic) ----
 // 1-D transform of n_lines lines: element k of line (a, b) is at data[a*stride_a + b*stride_b + k*stride_k],
 // a in [0, n_a), b in [0, n_b).  tmp: same size as data.

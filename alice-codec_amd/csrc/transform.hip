@@ -711,6 +711,207 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage-level Wavelet2D / Wavelet3D on caller-shaped i32 data (src/wavelet.rs:292-340, 392-484): the same tile
+// structure as the pipeline kernels with the reference's exact arithmetic (wrapping i32 sums, 64-bit products), so any
+// i32 values are allowed.  Three planes per workgroup play the part the three colour channels play above.
+// Shapes: even width and height of at least 6 (one reflection covers the halo), even depth; everything else (odd
+// lengths with the reference's dropped tail sample, tiny sizes) stays on generic.hip.
+// ------------------------------------------------------------------------------------------------
+constexpr int S_LP = F_TW + 1;   // LDS row pitch in dwords (one i32 sample each)
+
+template <int NS>
+__global__ __launch_bounds__(F_THREADS) void stage_fwd_xy_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                                        int w, int h, unsigned planes, unsigned tiles_x,
+                                                                        unsigned tiles_per_plane, Coeffs cf) {
+    constexpr int H = NS;
+    constexpr int ER = F_TH + 2 * H;
+    constexpr int NL = F_SEG + 2 * H;
+    extern __shared__ int lds[];   // [3][ER][S_LP]
+    const int tid = threadIdx.x;
+    const unsigned groups = (planes + 2u) / 3u;
+    const unsigned l = xcd_logical_block(tiles_per_plane * groups);
+    if (l == 0xFFFFFFFFu) return;
+    const unsigned g = l / tiles_per_plane, ti = l % tiles_per_plane;
+    const int gx0 = (int)(ti % tiles_x) * F_TW, gy0 = (int)(ti / tiles_x) * F_TH;
+    const size_t plane = (size_t)w * h;
+    // stage A: rows (src/wavelet.rs:401-405), a 16-sample segment + halo per thread, one plane after the other
+    if (tid < ER * F_NSEG) {
+        const int r = tid >> 3, s = tid & 7;
+        const int gy = reflect_idx(gy0 - H + r, h);
+        for (int pl = 0; pl < 3; ++pl) {
+            const unsigned p = g * 3u + (unsigned)pl;
+            if (p >= planes) break;
+            const int32_t* row = in + (size_t)p * plane + (size_t)gy * w;
+            int v[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) v[k] = row[reflect_idx(gx0 - H + s * F_SEG + k, w)];
+            lift_regs<NL, NS, true, false>(v, cf);
+            int* L = lds + (pl * ER + r) * S_LP;
+#pragma unroll
+            for (int j = 0; j < F_SEG / 2; ++j) { L[s * 8 + j] = v[H + 2 * j]; L[64 + s * 8 + j] = v[H + 2 * j + 1]; }
+        }
+    }
+    __syncthreads();
+    // stage B: columns (:408-417), one deinterleaved column of one plane per thread
+    {
+        const int xq = tid & 127, pl = tid >> 7;
+        const unsigned p = g * 3u + (unsigned)pl;
+        const int par = xq >> 6, j = xq & 63;
+        const int gxp = gx0 / 2 + j;
+        const int hw = w / 2, hh = h / 2;
+        if (p < planes && gxp < hw) {
+            int v[ER];
+            const int* L = lds + (pl * ER) * S_LP + xq;
+#pragma unroll
+            for (int r = 0; r < ER; ++r) v[r] = L[r * S_LP];
+            lift_regs<ER, NS, true, false>(v, cf);
+            int32_t* o = out + (size_t)p * plane + (size_t)par * hw + gxp;
+#pragma unroll
+            for (int k = 0; k < F_TH; ++k) {
+                const int gy = gy0 + k;
+                if (gy < h) o[(size_t)((gy & 1) * hh + (gy >> 1)) * w] = v[H + k];
+            }
+        }
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(I_THREADS) void stage_inv_xy_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                                        int w, int h, unsigned planes, unsigned tiles_x,
+                                                                        unsigned tiles_per_plane, Coeffs cf) {
+    constexpr int H = NS;
+    constexpr int ER = I_TH + 2 * H;
+    constexpr int EC = I_TW + 2 * H;
+    constexpr int ECh = EC / 2;
+    constexpr int NL = I_SEG + 2 * H;
+    __shared__ __attribute__((aligned(16))) int lds[3 * ER * I_LW];
+    const int tid = threadIdx.x;
+    const unsigned groups = (planes + 2u) / 3u;
+    const unsigned l = xcd_logical_block(tiles_per_plane * groups);
+    if (l == 0xFFFFFFFFu) return;
+    const unsigned g = l / tiles_per_plane, ti = l % tiles_per_plane;
+    const int gx0 = (int)(ti % tiles_x) * I_TW, gy0 = (int)(ti / tiles_x) * I_TH;
+    const size_t plane = (size_t)w * h;
+    const int hw = w / 2, hh = h / 2;
+    const int gpx0 = (gx0 - H) / 2;
+    // stage A: inverse columns (src/wavelet.rs:319-329 order: columns first), one extended column of one plane per thread
+    if (tid < 3 * EC) {
+        const int pl = tid / EC, xq = tid % EC;
+        const unsigned p = g * 3u + (unsigned)pl;
+        if (p < planes) {
+            const int par = xq / ECh, j = xq % ECh;
+            const int px = reflect_idx(2 * (gpx0 + j) + par, w);
+            const int32_t* src = in + (size_t)p * plane + (size_t)par * hw + (px >> 1);
+            int v[ER];
+#pragma unroll
+            for (int k = 0; k < ER; ++k) {
+                const int gy = reflect_idx(gy0 - H + k, h);
+                v[k] = src[(size_t)((gy & 1) * hh + (gy >> 1)) * w];
+            }
+            lift_regs<ER, NS, true, true>(v, cf);
+            int* L = lds + (pl * ER) * I_LW + par * I_HO + j;
+#pragma unroll
+            for (int k = 0; k < ER; ++k) L[k * I_LW] = v[k];
+        }
+    }
+    __syncthreads();
+    // stage B: inverse rows, 8 interleaved output samples per thread and plane
+    {
+        const int r = tid / I_NSEG, s = tid % I_NSEG;
+        const int gy = gy0 + r, gxs = gx0 + s * I_SEG;
+        if (gy < h && gxs < w) {
+            for (int pl = 0; pl < 3; ++pl) {
+                const unsigned p = g * 3u + (unsigned)pl;
+                if (p >= planes) break;
+                int v[NL];
+                const int* Lc = lds + (pl * ER + r + H) * I_LW + s * 4;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int4 a = *(const int4*)(Lc + half * I_HO);
+                    const int4 b = *(const int4*)(Lc + half * I_HO + 4);
+                    const int w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int q = 0; q < NL / 2; ++q) v[2 * q + half] = w8[q];
+                }
+                lift_regs<NL, NS, true, true>(v, cf);
+                int32_t* o = out + (size_t)p * plane + (size_t)gy * w + gxs;
+#pragma unroll
+                for (int k = 0; k < I_SEG; ++k)
+                    if (gxs + k < w) o[k] = v[H + k];
+            }
+        }
+    }
+}
+
+// Temporal pass of Wavelet3D (src/wavelet.rs:421-437 forward, :447-463 inverse) as a stream over frame pairs, one
+// pixel per thread, exact arithmetic; `in` and `out` are different buffers (the transform deinterleaves along t).
+template <int NS, bool INVERSE>
+__global__ __launch_bounds__(256) void stage_t_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, size_t plane,
+                                                      int depth, Coeffs cf) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= plane) return;
+    const int half = depth / 2;
+    const int32_t* s = in + idx;
+    int32_t* o = out + idx;
+    auto d = [](int a, int b, int c) { return lift_delta<true>(a, b, c); };
+    if (!INVERSE) {
+        int o1p = 0, e1p = 0, o2pp = 0;
+        int ce = s[0], co = s[plane];
+        for (int k = 0; k < half; ++k) {
+            const int ne = (k + 1 < half) ? s[(size_t)(2 * k + 2) * plane] : ce;
+            const int no = (k + 1 < half) ? s[(size_t)(2 * k + 3) * plane] : 0;
+            const int o1 = wadd(co, d(ce, ne, cf.c[0]));
+            const int e1 = wadd(ce, d(k == 0 ? o1 : o1p, o1, cf.c[1]));
+            if (NS == 2) {
+                o[(size_t)k * plane] = e1; o[(size_t)(half + k) * plane] = o1;
+            } else if (k >= 1) {
+                const int o2 = wadd(o1p, d(e1p, e1, cf.c[2]));
+                const int e2 = wadd(e1p, d(k == 1 ? o2 : o2pp, o2, cf.c[3]));
+                o[(size_t)(k - 1) * plane] = e2; o[(size_t)(half + k - 1) * plane] = o2;
+                o2pp = o2;
+            }
+            o1p = o1; e1p = e1; ce = ne; co = no;
+        }
+        if (NS == 4) {
+            const int o2 = wadd(o1p, d(e1p, e1p, cf.c[2]));
+            const int e2 = wadd(e1p, d(half == 1 ? o2 : o2pp, o2, cf.c[3]));
+            o[(size_t)(half - 1) * plane] = e2; o[(size_t)(2 * half - 1) * plane] = o2;
+        }
+    } else {
+        const int c0 = -cf.c[0], c1 = -cf.c[1], c2 = -cf.c[2], c3 = -cf.c[3];
+        int o2p = 0, e1p = 0, o1pp = 0, e0pp = 0;
+        for (int k = 0; k < half; ++k) {
+            const int lv = s[(size_t)k * plane], hv = s[(size_t)(half + k) * plane];
+            if (NS == 4) {
+                const int e1 = wadd(lv, d(k == 0 ? hv : o2p, hv, c3));
+                if (k >= 1) {
+                    const int o1 = wadd(o2p, d(e1p, e1, c2));
+                    const int e0 = wadd(e1p, d(k == 1 ? o1 : o1pp, o1, c1));
+                    o[(size_t)(2 * (k - 1)) * plane] = e0;
+                    if (k >= 2) o[(size_t)(2 * (k - 2) + 1) * plane] = wadd(o1pp, d(e0pp, e0, c0));
+                    o1pp = o1; e0pp = e0;
+                }
+                o2p = hv; e1p = e1;
+            } else {
+                const int e0 = wadd(lv, d(k == 0 ? hv : o2p, hv, c1));
+                o[(size_t)(2 * k) * plane] = e0;
+                if (k >= 1) o[(size_t)(2 * (k - 1) + 1) * plane] = wadd(o2p, d(e1p, e0, c0));
+                o2p = hv; e1p = e0;
+            }
+        }
+        if (NS == 4) {
+            const int o1 = wadd(o2p, d(e1p, e1p, c2));
+            const int e0 = wadd(e1p, d(half == 1 ? o1 : o1pp, o1, c1));
+            o[(size_t)(2 * (half - 1)) * plane] = e0;
+            if (half >= 2) o[(size_t)(2 * (half - 2) + 1) * plane] = wadd(o1pp, d(e0pp, e0, c0));
+            o[(size_t)(2 * (half - 1) + 1) * plane] = wadd(o1, d(e0, e0, c0));
+        } else {
+            o[(size_t)(2 * (half - 1) + 1) * plane] = wadd(o2p, d(e1p, e1p, c0));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 
@@ -819,6 +1020,60 @@ bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wave
         else inv_launch<2, false, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
     }
     return true;
+}
+
+
+bool stage_tiles_eligible(uint64_t w, uint64_t h, uint64_t depth, int ndim) {
+    if (ndim < 2 || (w & 1) || (h & 1) || w < 6 || h < 6) return false;
+    if (w * h > (1ull << 30) || depth > 0x7FFFFFFFull || depth == 0) return false;
+    if (ndim >= 3 && depth > 1 && (depth & 1)) return false;      // an odd temporal length drops its tail sample: generic path
+    const uint64_t groups = (depth + 2) / 3;
+    if (((w + I_TW - 1) / I_TW) * ((h + I_TH - 1) / I_TH) * groups > 0x7FFFFFF0ull) return false;
+    return true;
+}
+
+// data -> result in `data`; tmp: same size.  ndim 2: every one of the `depth` planes is transformed on its own.
+void launch_stage_wavelet(int32_t* d_data, int32_t* d_tmp, uint64_t w, uint64_t h, uint64_t depth, int ndim, int wavelet,
+                          bool inverse, hipStream_t st) {
+    const LiftSteps ls = lift_steps(wavelet);
+    const Coeffs cf = to_coeffs(ls);
+    const size_t plane = (size_t)w * h;
+    const unsigned planes = (unsigned)depth, groups = (planes + 2) / 3;
+    const bool temporal = ndim >= 3 && depth >= 2;
+    const size_t ldsf = (size_t)3 * (F_TH + 2 * ls.n) * S_LP * sizeof(int);
+    auto fwd_xy = [&](const int32_t* a, int32_t* b) {
+        const unsigned tx = (unsigned)((w + F_TW - 1) / F_TW), ty = (unsigned)((h + F_TH - 1) / F_TH);
+        dim3 grid(xcd_grid((unsigned long long)tx * ty * groups));
+        if (ls.n == 4) {
+            static const bool ok = set_dyn_lds(stage_fwd_xy_kernel<4>, (size_t)3 * (F_TH + 8) * S_LP * sizeof(int)); (void)ok;
+            hipLaunchKernelGGL((stage_fwd_xy_kernel<4>), grid, dim3(F_THREADS), ldsf, st, a, b, (int)w, (int)h, planes, tx, tx * ty, cf);
+        } else {
+            static const bool ok = set_dyn_lds(stage_fwd_xy_kernel<2>, (size_t)3 * (F_TH + 4) * S_LP * sizeof(int)); (void)ok;
+            hipLaunchKernelGGL((stage_fwd_xy_kernel<2>), grid, dim3(F_THREADS), ldsf, st, a, b, (int)w, (int)h, planes, tx, tx * ty, cf);
+        }
+    };
+    auto inv_xy = [&](const int32_t* a, int32_t* b) {
+        const unsigned tx = (unsigned)((w + I_TW - 1) / I_TW), ty = (unsigned)((h + I_TH - 1) / I_TH);
+        dim3 grid(xcd_grid((unsigned long long)tx * ty * groups));
+        if (ls.n == 4) hipLaunchKernelGGL((stage_inv_xy_kernel<4>), grid, dim3(I_THREADS), 0, st, a, b, (int)w, (int)h, planes, tx, tx * ty, cf);
+        else hipLaunchKernelGGL((stage_inv_xy_kernel<2>), grid, dim3(I_THREADS), 0, st, a, b, (int)w, (int)h, planes, tx, tx * ty, cf);
+    };
+    auto t_pass = [&](const int32_t* a, int32_t* b, bool inv) {
+        dim3 grid((unsigned)((plane + 255) / 256));
+        if (ls.n == 4) { if (inv) hipLaunchKernelGGL((stage_t_kernel<4, true>), grid, dim3(256), 0, st, a, b, plane, (int)depth, cf);
+                         else hipLaunchKernelGGL((stage_t_kernel<4, false>), grid, dim3(256), 0, st, a, b, plane, (int)depth, cf); }
+        else { if (inv) hipLaunchKernelGGL((stage_t_kernel<2, true>), grid, dim3(256), 0, st, a, b, plane, (int)depth, cf);
+               else hipLaunchKernelGGL((stage_t_kernel<2, false>), grid, dim3(256), 0, st, a, b, plane, (int)depth, cf); }
+    };
+    const size_t bytes = plane * depth * sizeof(int32_t);
+    if (!inverse) {
+        fwd_xy(d_data, d_tmp);
+        if (temporal) t_pass(d_tmp, d_data, false);
+        else (void)hipMemcpyAsync(d_data, d_tmp, bytes, hipMemcpyDeviceToDevice, st);
+    } else {
+        if (temporal) { t_pass(d_data, d_tmp, true); inv_xy(d_tmp, d_data); }
+        else { inv_xy(d_data, d_tmp); (void)hipMemcpyAsync(d_data, d_tmp, bytes, hipMemcpyDeviceToDevice, st); }
+    }
 }
 
 }  // namespace alice

@@ -224,6 +224,13 @@ int alice_codec_dev_forward_symbols(const void *d_rgb, uint32_t width, uint32_t 
  * (src/pipeline.rs:597-621) */
 int alice_codec_dev_inverse_symbols(const void *d_symbols, uint32_t width, uint32_t height, uint32_t frames,
                                     uint8_t wavelet_type, const int32_t step[3], void *d_rgb, void *hip_stream);
+/* Wavelet3D::forward / inverse (src/wavelet.rs:392-484) of a device-resident i32 volume [depth][height][width], in place
+ * for the caller; d_tmp: scratch of the same size.  Any i32 values (wrapping sums, 64-bit products).  Even width and
+ * height >= 6 with an even depth run two tiled passes over the data; other shapes the per-axis kernels. */
+int alice_codec_dev_wavelet3d_forward(uint8_t wavelet_type, void *d_volume, void *d_tmp, uint64_t width, uint64_t height,
+                                      uint64_t depth, void *hip_stream);
+int alice_codec_dev_wavelet3d_inverse(uint8_t wavelet_type, void *d_volume, void *d_tmp, uint64_t width, uint64_t height,
+                                      uint64_t depth, void *hip_stream);
 /* build_histogram (src/quant.rs:587-600) of n device symbols -> d_hist[256] (u32, device) */
 int alice_codec_dev_histogram(const void *d_symbols, uint64_t n, void *d_hist, void *hip_stream);
 /* capacity that alice_codec_dev_rans_encode needs for n symbols with this histogram (NULL: worst case) */

@@ -230,6 +230,46 @@ def test_wavelet2d_3d(gpu_codec, oracle_mod):
             assert np.array_equal(gpu_codec.Wavelet3D(gpu_codec.WaveletType(k)).inverse(f, w, h, d), oracle_mod.wavelet3d(k, f, w, h, d, inverse=True))
 
 
+def test_stage_wavelets_on_tile_kernels(gpu_codec, oracle_mod):
+    """Wavelet2D / Wavelet3D of caller-shaped i32 data through the tile kernels' exact instances (even width and height
+    >= 6, even depth): any i32 values incl. the extremes (wrapping sums, 64-bit products, src/wavelet.rs:193-194), tiles
+    that overhang the image, volumes whose plane count is not a multiple of the three planes a workgroup takes; and the
+    device-pointer entry points alice_codec_dev_wavelet3d_*."""
+    import torch
+    rng = np.random.default_rng(1212)
+    lib = gpu_codec.load_library()
+
+    def values(n, kind):
+        if kind == 0:
+            return rng.integers(-1000, 1000, n).astype(np.int32)
+        v = rng.integers(-2**31, 2**31, n, dtype=np.int64).astype(np.int32)
+        v[:: 97] = 2**31 - 1
+        v[5:: 89] = -2**31
+        return v
+
+    for k in (0, 1, 2):
+        for (w, h) in ((6, 6), (8, 6), (130, 42), (256, 96), (98, 34), (1920, 1080)):
+            img = values(w * h, k & 1)
+            f = gpu_codec.Wavelet2D(gpu_codec.WaveletType(k)).forward(img, w, h)
+            assert np.array_equal(f, oracle_mod.wavelet2d(k, img, w, h)), (k, w, h)
+            assert np.array_equal(gpu_codec.Wavelet2D(gpu_codec.WaveletType(k)).inverse(f, w, h), oracle_mod.wavelet2d(k, f, w, h, inverse=True)), (k, w, h)
+        for (w, h, d) in ((6, 6, 2), (32, 32, 8), (16, 10, 70), (130, 44, 6), (96, 32, 4), (200, 90, 10), (64, 64, 1)):
+            vol = values(w * h * d, (k + d) & 1)
+            f = gpu_codec.Wavelet3D(gpu_codec.WaveletType(k)).forward(vol, w, h, d)
+            assert np.array_equal(f, oracle_mod.wavelet3d(k, vol, w, h, d)), (k, w, h, d)
+            assert np.array_equal(gpu_codec.Wavelet3D(gpu_codec.WaveletType(k)).inverse(f, w, h, d), oracle_mod.wavelet3d(k, f, w, h, d, inverse=True)), (k, w, h, d)
+    # device pointers, incl. a shape the tiles do not cover (odd width: per-axis kernels behind the same entry point)
+    for (w, h, d) in ((130, 44, 6), (33, 20, 4)):
+        vol = values(w * h * d, 1)
+        dv = torch.from_numpy(vol.copy()).cuda()
+        tmp = torch.empty_like(dv)
+        assert lib.alice_codec_dev_wavelet3d_forward(1, dv.data_ptr(), tmp.data_ptr(), w, h, d, None) == 0
+        ref = oracle_mod.wavelet3d(1, vol, w, h, d)
+        assert np.array_equal(dv.cpu().numpy(), ref), (w, h, d)
+        assert lib.alice_codec_dev_wavelet3d_inverse(1, dv.data_ptr(), tmp.data_ptr(), w, h, d, None) == 0
+        assert np.array_equal(dv.cpu().numpy(), oracle_mod.wavelet3d(1, ref, w, h, d, inverse=True)), (w, h, d)
+
+
 def test_quantizers_symbols_histogram(gpu_codec, oracle_mod):
     rng = np.random.default_rng(13)
     vals = np.concatenate([rng.integers(-10000, 10001, 5000), [0, 1, -1, 2**31 - 1, -2**31, -2**31 + 1]]).astype(np.int32)
