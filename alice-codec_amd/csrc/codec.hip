@@ -334,12 +334,12 @@ InverseBounds inverse_bounds(int wavelet, const int32_t step[3]) {
 struct EncodeWork {
     ChunkDims d{};
     int n_chunks = 0;
-    uint64_t cap = 0, alc_stride = 0;
+    uint64_t cap[3] = {0, 0, 0}, alc_stride = 0;   // stream regions of the Y, Co, Cg chains of a chunk
     DevBuf mid, tmp, sym, hist, tables, results, alc, sizes, planes;
 };
 
 int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks) {
-    w.d = d; w.n_chunks = n_chunks; w.cap = 0; w.alc_stride = 0;
+    w.d = d; w.n_chunks = n_chunks; w.cap[0] = w.cap[1] = w.cap[2] = 0; w.alc_stride = 0;
     TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
     TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
     TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
@@ -349,14 +349,14 @@ int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks) {
     return kOk;
 }
 
-// .alc buffers for a per-chain capacity (re-allocated only when it grows).  A chunk's buffer is
-// [kStreamHead bytes][3 regions of cap bytes]: the chains write their streams at the tails of the regions and the
-// compaction moves them, in place, behind the header at the front.
-int encode_work_set_cap(EncodeWork& w, uint64_t cap) {
-    if (cap <= w.cap && w.alc.p) return kOk;
+// .alc buffers for the capacities of the three chains of a chunk (re-allocated only when one grows).  A chunk's buffer is
+// [kStreamHead bytes][region Y][region Co][region Cg]: the chains write their streams at the tails of their regions and
+// the compaction moves them, in place, behind the header at the front.
+int encode_work_set_cap(EncodeWork& w, const uint64_t cap[3]) {
+    if (w.alc.p && cap[0] <= w.cap[0] && cap[1] <= w.cap[1] && cap[2] <= w.cap[2]) return kOk;
     w.alc.reset();
-    w.cap = cap;
-    w.alc_stride = round_up(kStreamHead + 3 * cap, 256);
+    for (int c = 0; c < 3; ++c) w.cap[c] = std::max(w.cap[c], cap[c]);
+    w.alc_stride = round_up(kStreamHead + w.cap[0] + w.cap[1] + w.cap[2], 256);
     TRY(w.alc.alloc((size_t)w.n_chunks * w.alc_stride + 256));  // slack: the compaction copy reads whole dwords
     return kOk;
 }
@@ -449,22 +449,23 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
             TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[1], st));
-    uint64_t cap = cap_override;
-    if (!cap) {
+    uint64_t cap[3] = {cap_override, cap_override, cap_override};
+    if (!cap_override) {
         std::vector<uint32_t> hist((size_t)B * 3 * 256);
         HIP_TRY(hipMemcpyAsync(hist.data(), w.hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (int c = 0; c < 3 * B; ++c) cap = std::max(cap, estimate_stream_cap(&hist[(size_t)c * 256], d.padded));
-        cap = std::min(round_up(cap, 256), worst_cap(d));
+        // one capacity per channel (the largest over the chunks): Y streams are about twice as long as Co / Cg streams
+        for (int c = 0; c < 3 * B; ++c) cap[c % 3] = std::max(cap[c % 3], estimate_stream_cap(&hist[(size_t)c * 256], d.padded));
+        for (int c = 0; c < 3; ++c) cap[c] = std::min(round_up(cap[c], 256), worst_cap(d));
         // test-only override (alice_codec_test_force_first_cap): pretend the estimate was far too small, to exercise
         // the overflow-and-retry path
-        if (const uint64_t forced = g_test_first_cap.load(std::memory_order_relaxed)) cap = forced;
+        if (const uint64_t forced = g_test_first_cap.load(std::memory_order_relaxed)) cap[0] = cap[1] = cap[2] = forced;
     }
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[2], st));
     launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.alc.as<uint8_t>(),
-                       w.cap, w.results.as<RansResult>(), 3 * B, st, w.alc_stride, kStreamHead);
+                       w.cap[0], w.results.as<RansResult>(), 3 * B, st, w.alc_stride, kStreamHead, 0xFFFFFFFFu, w.cap[1], w.cap[2]);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[3], st));
     launch_write_headers(w.alc.as<uint8_t>(), w.alc_stride, d, wavelet, step, w.hist.as<uint32_t>(),
                          w.results.as<RansResult>(), w.sizes.as<unsigned long long>(), B, st);

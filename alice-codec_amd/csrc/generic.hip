@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict_
 // began or earlier, so it can only overlap sources that have already been read.
 constexpr int kCompactThreads = 1024, kCompactVecs = 4;
 __global__ __launch_bounds__(kCompactThreads) void compact_streams_kernel(uint8_t* __restrict__ alc, unsigned long long alc_stride,
-                                                                         unsigned long long head_bytes, unsigned long long cap,
+                                                                         unsigned long long head_bytes, unsigned long long cap0,
+                                                                         unsigned long long cap1, unsigned long long cap2,
                                                                          const RansResult* __restrict__ res) {
     const int chunk = blockIdx.x;
     const unsigned tid = threadIdx.x;
@@ -506,8 +507,10 @@ __global__ __launch_bounds__(kCompactThreads) void compact_streams_kernel(uint8_
     for (int c = 0; c < 3; ++c) {
         // never touch memory for a chain that overflowed its region (its length exceeds the capacity)
         const RansResult rr = res[chunk * 3 + c];
+        const unsigned long long cap = c == 0 ? cap0 : (c == 1 ? cap1 : cap2);
+        const unsigned long long region_end = c == 0 ? cap0 : (c == 1 ? cap0 + cap1 : cap0 + cap1 + cap2);
         const unsigned long long len = ((rr.flags & kRansOverflow) || rr.len > cap) ? 0ull : rr.len;
-        const uint8_t* src = base + head_bytes + (size_t)(c + 1) * cap - len;
+        const uint8_t* src = base + head_bytes + (size_t)region_end - len;
         // bytes up to the first 16-byte boundary of dst, then 16 B stores fed by (possibly unaligned) 4 B loads
         unsigned long long head = (16u - (unsigned)((uintptr_t)dst & 15u)) & 15u;
         if (head > len) head = len;
@@ -595,11 +598,12 @@ void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& 
     hipLaunchKernelGGL(write_headers_kernel, dim3(n_chunks), dim3(256), 0, st, d_alc, (unsigned long long)alc_stride, d,
                        wavelet, step, d_hist, d_results, d_sizes);
 }
-void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, uint64_t head, uint64_t cap,
+void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, uint64_t head, const uint64_t cap[3],
                             const RansResult* d_results, int n_chunks, hipStream_t st) {
     if (n_chunks <= 0) return;
     hipLaunchKernelGGL(compact_streams_kernel, dim3(n_chunks), dim3(kCompactThreads), 0, st, d_alc,
-                       (unsigned long long)alc_stride, (unsigned long long)head, (unsigned long long)cap, d_results);
+                       (unsigned long long)alc_stride, (unsigned long long)head, (unsigned long long)cap[0],
+                       (unsigned long long)cap[1], (unsigned long long)cap[2], d_results);
 }
 
 }  // namespace alice

@@ -50,9 +50,12 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
 // the stream is the last results[c].len bytes of that region.  group_stride == 0: region c starts at
 // out + c*cap.  Otherwise chains 3g, 3g+1, 3g+2 write into chunk g's .alc buffer: region start =
 // out + g*group_stride + group_head + (c % 3)*cap.  Chains c >= n_split encode n - 1 symbols.
+// cap_co / cap_cg (grouped mode only, 0 = same as cap): the second and third chain of a group get regions of their own
+// sizes, laid out back to back behind the first (Y streams are about twice as long as Co / Cg streams).
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
-                        uint64_t group_stride = 0, uint64_t group_head = 0, unsigned n_split = 0xFFFFFFFFu);
+                        uint64_t group_stride = 0, uint64_t group_head = 0, unsigned n_split = 0xFFFFFFFFu,
+                        uint64_t cap_co = 0, uint64_t cap_cg = 0);
 // out_j[k] = in[4k + j] for the four sub-sequences of an interleaved stream (out_j = out + j*stride)
 void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t stride, hipStream_t st);
 // InterleavedRansDecoder::decode_n order (src/rans.rs:501-519): symbol k of stream j lands at
@@ -110,7 +113,7 @@ void launch_sq_diff_sum(const uint8_t* a, const uint8_t* b, uint64_t n, unsigned
 // Each chunk's .alc buffer holds, behind `head` bytes, three cap-sized regions with a stream at the tail of
 // each; moves the streams, in place, to directly behind the 3138-byte header slot.
 constexpr uint64_t kStreamHead = 3328;   // >= kAlcHeaderBytes, multiple of 256
-void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, uint64_t head, uint64_t cap,
+void launch_compact_streams(uint8_t* d_alc, uint64_t alc_stride, uint64_t head, const uint64_t cap[3],
                             const RansResult* d_results, int n_chunks, hipStream_t st);
 // fills the 3138-byte headers on the device (magic, dims, per-channel fields, histograms)
 void launch_write_headers(uint8_t* d_alc, uint64_t alc_stride, const ChunkDims& d, int wavelet, int32_t step,

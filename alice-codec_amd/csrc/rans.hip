@@ -236,11 +236,12 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                                                          unsigned long long n_first,
                                                          const RansTable* __restrict__ tables,
                                                          uint8_t* __restrict__ out_base,
-                                                         unsigned long long cap,
+                                                         unsigned long long cap0,
                                                          unsigned long long group_stride,
                                                          unsigned long long group_head,
                                                          unsigned n_split,
-                                                         RansResult* __restrict__ results) {
+                                                         RansResult* __restrict__ results,
+                                                         unsigned long long cap1, unsigned long long cap2) {
     __shared__ uint4 tab_a[256];  // xmax, xmax8, rcp, rsh
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
     __shared__ __attribute__((aligned(16))) uint8_t tile[kEncTile];
@@ -254,8 +255,11 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     const RansTable* __restrict__ tbl = tables + chain;
     // group_stride == 0: regions back to back.  Otherwise the three chains of chunk g write into the chunk's own
     // .alc buffer, behind `group_head` bytes kept free for the header (the streams are compacted in place later).
-    uint8_t* const region = group_stride == 0ull ? out_base + (size_t)chain * cap
-                                                 : out_base + (size_t)(chain / 3) * group_stride + group_head + (size_t)(chain % 3) * cap;
+    const int gch = chain % 3;
+    const unsigned long long cap = group_stride == 0ull ? cap0 : (gch == 0 ? cap0 : (gch == 1 ? cap1 : cap2));
+    uint8_t* const region = group_stride == 0ull ? out_base + (size_t)chain * cap0
+                                                 : out_base + (size_t)(chain / 3) * group_stride + group_head +
+                                                       (gch == 0 ? 0ull : (gch == 1 ? cap0 : cap0 + cap1));
     uint8_t* const out_end = region + cap;
     // lanes that have nothing to emit store to a private byte at the unused front of the region instead
     // of branching around the store; the capacity test keeps real bytes 64 bytes away from it
@@ -730,13 +734,13 @@ static unsigned chain_lds_pad(int n_chains, unsigned static_lds) {
 
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
-                        uint64_t group_stride, uint64_t group_head, unsigned n_split) {
+                        uint64_t group_stride, uint64_t group_head, unsigned n_split, uint64_t cap_co, uint64_t cap_cg) {
     if (n_chains <= 0) return;
     auto kern = n_chains <= 1024 ? rans_encode_kernel<true> : rans_encode_kernel<false>;
     hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, 9216u), st, d_sym,
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
                        (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, n_split,
-                       d_results);
+                       d_results, (unsigned long long)(cap_co ? cap_co : cap), (unsigned long long)(cap_cg ? cap_cg : cap));
 }
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {

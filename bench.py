@@ -177,7 +177,7 @@ def main() -> None:
         fixed = px_chunk * 12 + (2 << 30)                                      # one chunk's transform scratch; slack
         if use_dist:
             fixed += 2 * max(world - 1, 1) * alc_stride                        # the root's receive ring
-        B = int((free_b * 0.93 - fixed) // per_chunk)
+        B = int((free_b * 0.95 - fixed) // per_chunk)
         B = max(1, min(B, 341))
         if use_dist:
             tb = torch.tensor([B], dtype=torch.int64, device=dev)
