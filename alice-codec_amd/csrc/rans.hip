@@ -228,6 +228,39 @@ __device__ __forceinline__ void ripple64(uint32_t& xin, uint32_t& xout, uint32_t
 #undef ALICE_RIPPLE_STEP
 }
 
+// The same 64 steps with ONE compare per step, for chains whose states stay in [2^23, 2^31 + 2^17): every symbol that
+// occurs has a frequency in 1..4096 (kTableVerified without the generic / diverges flags) and the chain started from
+// 2^23.  Then the renormalisation shift needs only one threshold per symbol:
+//   freq <= 16: freq << 19 <= 2^23 <= x, the first shift always happens:   k = 8 + 8 * (x >= freq << 27)
+//   freq >= 17: freq << 27 > 2^31 + 2^17 > x, the second never happens:    k = 8 * (x >= freq << 19)
+// (x < 2^31 + 2^17: x' = (q << 12) + r + cum with q < 2^19, r < freq <= 4096, cum < 2^16.)  thr / k0 / k1 are the lane's
+// threshold and the two shift candidates.  9 issue slots per symbol instead of 11.
+__device__ __forceinline__ void ripple64_clean(uint32_t& xin, uint32_t& xout, uint32_t thr, uint32_t k0, uint32_t k1,
+                                               uint32_t rcp, uint32_t rsh, int32_t g, uint32_t cprev) {
+    uint32_t k, y, q;
+#define ALICE_RIPPLE_STEP                                                            \
+    "v_add_u32_dpp %[xin], %[xout], %[cprev] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_cmp_ge_u32_e32 vcc, %[xin], %[thr]\n\t"                                     \
+    "s_nop 1\n\t"                                                                  \
+    "v_cndmask_b32_e32 %[k], %[k0], %[k1], vcc\n\t"                                \
+    "v_lshrrev_b32_e32 %[y], %[k], %[xin]\n\t"                                     \
+    "v_mul_hi_u32 %[q], %[y], %[rcp]\n\t"                                          \
+    "v_lshrrev_b32_e32 %[q], %[rsh], %[q]\n\t"                                     \
+    "v_mad_i32_i24 %[xout], %[q], %[g], %[y]\n\t"                                  \
+    "s_nop 1\n\t"
+#define ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP ALICE_RIPPLE_STEP ALICE_RIPPLE_STEP ALICE_RIPPLE_STEP
+#define ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP4 ALICE_RIPPLE_STEP4
+    asm volatile(
+        "s_nop 1\n\t"
+        ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP16 ALICE_RIPPLE_STEP16
+        : [xin] "+v"(xin), [xout] "+v"(xout), [k] "=&v"(k), [y] "=&v"(y), [q] "=&v"(q)
+        : [thr] "v"(thr), [k0] "v"(k0), [k1] "v"(k1), [rcp] "v"(rcp), [rsh] "v"(rsh), [g] "v"(g), [cprev] "v"(cprev)
+        : "vcc");
+#undef ALICE_RIPPLE_STEP16
+#undef ALICE_RIPPLE_STEP4
+#undef ALICE_RIPPLE_STEP
+}
+
 // kExclusive: the kernel claims more than half of the SIMD's 512 registers (an AGPR clobber; nothing uses them), so
 // the dispatcher cannot put two chains on one SIMD -- see launch_rans_encode.
 template <bool kExclusive>
@@ -345,7 +378,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                 const uint32_t cbias = curp.eb.y;
                 uint32_t xout = 0u;
                 const uint32_t cprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cbias, 0x138, 0xf, 0xf, true);
-                ripple64(xin, xout, xmax, xmax8, rcp, rsh, g, cprev);
+                const bool small_f = xmax <= kRansL;            // freq <= 16
+                const uint32_t k0 = small_f ? 8u : 0u;
+                ripple64_clean(xin, xout, small_f ? xmax8 : xmax, k0, k0 + 8u, rcp, rsh, g, cprev);
                 const bool c1 = xin >= xmax;
                 const bool c2 = xin >= xmax8;
                 const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
