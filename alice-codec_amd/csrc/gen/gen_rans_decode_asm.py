@@ -74,6 +74,11 @@ e("s_lshl_b64 s[62:63], s[62:63], s71")
 e("s_sub_u32 s72, 31, s71")   # 64 - shift - 33
 e("2:")
 # s72 holds (valid window bits - 33): the borrow of the one subtraction per symbol pair is the refill condition
+# Symbols go in pairs.  At the start of a pair the window holds at least 33 valid bits, so its upper dword s63 is all
+# stream.  s60 takes a copy of it ONCE per pair: the even symbol's shift of {s60:s61} feeds the state and leaves
+# s60 = s63 << sh with 32 - sh >= 16 valid bits on top, enough for the odd symbol (a symbol consumes at most 16 bits);
+# the window itself is shifted once per pair by the sum of the two shifts, which the refill test needs anyway.
+# (Half an issue slot per symbol less than copying and shifting the window for every symbol.)
 for lane in range(64):
     sh = "s77" if lane & 1 else "s71"
     e("s_bfe_u32 s76, s61, 0x60006")
@@ -84,12 +89,14 @@ for lane in range(64):
     e("s_mul_hi_u32 s70, s67, s61")
     e("s_add_u32 s61, s70, s69")
     e("s_flbit_i32_b32 m0, s61")
-    e("s_mov_b32 s60, s63")
+    # one instruction must sit between the SALU write of M0 and s_movrels (wait state): the copy for the even symbol,
+    # a no-op for the odd one
+    e("s_mov_b32 s60, s63" if not lane & 1 else "s_nop 0")
     e(f"s_movrels_b32 {sh}, s80")
     e(f"s_lshl_b64 s[60:61], s[60:61], {sh}")
-    e(f"s_lshl_b64 s[62:63], s[62:63], {sh}")
     if lane & 1:
         e("s_add_u32 s78, s71, s77")
+        e("s_lshl_b64 s[62:63], s[62:63], s78")
         e("s_sub_u32 s72, s72, s78")            # SCC = borrow <=> fewer than 33 valid bits left
         e(f"s_cbranch_scc1 3{lane:02d}f")
         e(f"4{lane:02d}:")
