@@ -711,6 +711,143 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4x: the same inverse tile with LANE-EXCHANGE row lifting.  In inv_xy_kernel a stage-B thread lifts its 8 pixels plus
+// NS halo samples on each side (16 samples to keep 8) because it cannot see its neighbours' intermediate values.  Here
+// the 16 lanes of a DPP row hold one tile row -- a left halo segment, twelve 8-pixel segments, a right halo segment --
+// and every lifting step fetches the one neighbour sample it needs with a row_shr / row_shl DPP move: a lane lifts exactly
+// its own 8 samples.  An output depends on inputs at most NS samples away and the halo lanes hold NS true samples next to
+// the tile (their far halves are never-read garbage), so lanes 1..12 end up with the same integers as the global pass.
+// Used whenever the packed-i16 tile of inv_xy_kernel<..., LDS16 = true> is not provably safe (e.g. q = 80).
+// ------------------------------------------------------------------------------------------------
+constexpr int X_THREADS = 512;          // 32 rows x 16 lanes in stage B
+constexpr int X_HO = 56, X_LW = 112;    // tile row: even samples at columns 2 .. 53 (+2 never-read columns each side), odd at 56 + ...
+
+// one inverse/forward lifting pass over the 8 samples of a lane (v[0] even), neighbours by DPP within the 16-lane row
+template <int NS, bool EXACT, bool INVERSE>
+__device__ __forceinline__ void lift_seg8_dpp(int (&v)[8], const Coeffs& cf) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k_step = INVERSE ? (NS - 1 - s) : s;
+        const int c = INVERSE ? -cf.c[k_step] : cf.c[k_step];
+        if ((k_step & 1) == 0) {  // predict: odd += d(even_left, even_right); v[7] needs the right neighbour's v[0]
+            const int right0 = __builtin_amdgcn_update_dpp(0, v[0], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 1; k < 8; k += 2) v[k] = wadd(v[k], lift_delta<EXACT>(v[k - 1], k + 1 < 8 ? v[k + 1] : right0, c));
+        } else {                  // update: even += d(odd_left, odd_right); v[0] needs the left neighbour's v[7]
+            const int left7 = __builtin_amdgcn_update_dpp(0, v[7], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) v[k] = wadd(v[k], lift_delta<EXACT>(k >= 1 ? v[k - 1] : left7, v[k + 1], c));
+        }
+    }
+}
+
+template <int NS, bool EDGE, bool EXACT, typename MidT>
+__global__ __launch_bounds__(X_THREADS) void inv_xy_dpp_kernel(const MidT* __restrict__ mid, uint8_t* __restrict__ rgb,
+                                                               ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
+    constexpr int H = NS;
+    constexpr int ER = I_TH + 2 * H;
+    constexpr int EC = I_TW + 2 * H;
+    constexpr int ECh = EC / 2;
+    __shared__ __attribute__((aligned(16))) int lds[3 * ER * X_LW];
+    const int tid = threadIdx.x;
+    int bx, by, t;
+    {
+        const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
+        const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
+        const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
+        const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
+        const unsigned lb = xcd_logical_block(per_frame * d.f);
+        if (lb == 0xFFFFFFFFu) return;
+        t = (int)(lb / per_frame);
+        int i = (int)(lb % per_frame);
+        if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
+        else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
+        else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
+        else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
+        else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
+    }
+    const int gx0 = bx * I_TW, gy0 = by * I_TH;
+    const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
+    const int gpx0 = (gx0 - H) / 2;
+
+    // stage A: as in inv_xy_kernel; extended column e = 2 j + par goes to tile column par * X_HO + j + (4 - H) / 2 + ...
+    // (the H halo samples of a side end right at the first / last real segment: sample e sits at even/odd column (e + 4 - H) / 2 + 2)
+    if (tid < 3 * EC) {
+        const int ch = tid / EC, xq = tid % EC;
+        const int par = xq / ECh, j = xq % ECh;
+        const int px = EDGE ? reflect_idx(2 * (gpx0 + j) + par, pw) : 2 * (gpx0 + j) + par;
+        int v[ER];
+        const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + (px >> 1);
+        const int gy_s = gy0 - H;
+        if (EDGE) {
+#pragma unroll
+            for (int k = 0; k < ER; ++k) {
+                const int gy = reflect_idx(gy_s + k, ph);
+                const int yy = (gy & 1) * hh + (gy >> 1);
+                v[k] = (int)src[(size_t)yy * pw];
+            }
+        } else {
+            const MidT* lo = src + (size_t)(gy_s >> 1) * pw;
+            const MidT* hi = lo + (size_t)hh * pw;
+#pragma unroll
+            for (int m = 0; m < ER / 2; ++m) { v[2 * m] = (int)lo[(size_t)m * pw]; v[2 * m + 1] = (int)hi[(size_t)m * pw]; }
+        }
+        lift_regs<ER, NS, EXACT, true>(v, cf);
+        // pair index of the sample inside the row that starts 8 samples left of the tile: (8 - H) / 2 + j
+        int* L = lds + (ch * ER) * X_LW + par * X_HO + (8 - H) / 2 + j;
+#pragma unroll
+        for (int k = 0; k < ER; ++k) L[k * X_LW] = v[k];
+    }
+    __syncthreads();
+
+    // stage B: lane s of a 16-lane row holds segment s - 1 (8 samples = 4 even + 4 odd: one ds_read_b128 per half)
+    {
+        const int r = tid >> 4, s = tid & 15;
+        const int gy = gy0 + r;
+        const int gxs = gx0 + (s - 1) * 8;
+        int y[8], co[8], cg[8];
+        auto fetch = [&](int ch, int (&dst)[8]) {
+            const int* Lc = lds + (ch * ER + r + H) * X_LW + s * 4;
+            const int4 a = s < 14 ? *(const int4*)Lc : make_int4(0, 0, 0, 0);
+            const int4 b = s < 14 ? *(const int4*)(Lc + X_HO) : make_int4(0, 0, 0, 0);
+            dst[0] = a.x; dst[2] = a.y; dst[4] = a.z; dst[6] = a.w;
+            dst[1] = b.x; dst[3] = b.y; dst[5] = b.z; dst[7] = b.w;
+        };
+        fetch(0, y); fetch(1, co); fetch(2, cg);
+        lift_seg8_dpp<NS, EXACT, true>(y, cf);
+        lift_seg8_dpp<NS, EXACT, true>(co, cf);
+        lift_seg8_dpp<NS, EXACT, true>(cg, cf);
+        if (s >= 1 && s <= 12 && (!EDGE || (gy < (int)d.h && gxs < (int)d.w))) {
+            uint8_t out[24];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                // `as i16` (src/pipeline.rs:608) then wrapping i16 arithmetic (src/color.rs:266-273)
+                const short yv = (short)y[kk], c_o = (short)co[kk], c_g = (short)cg[kk];
+                const short tt = (short)(yv - (short)(c_g >> 1));
+                const short g = (short)(c_g + tt);
+                const short b = (short)(tt - (short)(c_o >> 1));
+                const short rr = (short)(c_o + b);
+                out[3 * kk] = (uint8_t)min(max((int)rr, 0), 255);
+                out[3 * kk + 1] = (uint8_t)min(max((int)g, 0), 255);
+                out[3 * kk + 2] = (uint8_t)min(max((int)b, 0), 255);
+            }
+            uint8_t* p = rgb + (((size_t)t * d.h + gy) * d.w + gxs) * 3;
+            if (aligned && (!EDGE || gxs + 8 <= (int)d.w)) {
+                uint32_t* p4 = (uint32_t*)p;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    p4[i] = (uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) |
+                            ((uint32_t)out[4 * i + 3] << 24);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    if (gxs + kk < (int)d.w) { p[3 * kk] = out[3 * kk]; p[3 * kk + 1] = out[3 * kk + 1]; p[3 * kk + 2] = out[3 * kk + 2]; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stage-level Wavelet2D / Wavelet3D on caller-shaped i32 data (src/wavelet.rs:292-340, 392-484): the same tile
 // structure as the pipeline kernels with the reference's exact arithmetic (wrapping i32 sums, 64-bit products), so any
 // i32 values are allowed.  Three planes per workgroup play the part the three colour channels play above.
@@ -995,6 +1132,12 @@ static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkD
     else { tm.iy0 = (int)ny; tm.iy1 = (int)ny; }  // everything is "top strip"
     const unsigned long long n_in = has_interior ? (unsigned long long)(ix1 - 1) * (iy1 - 1) : 0ull;
     const unsigned long long n_edge = (unsigned long long)nx * ny - n_in;
+    // packed-i16 tile provable: inv_xy_kernel (25 KB of LDS, five workgroups per CU); otherwise the lane-exchange kernel
+    if (!LDS16) {
+        if (n_in) hipLaunchKernelGGL((inv_xy_dpp_kernel<NS, false, EXACT, MidT>), dim3(xcd_grid(n_in * d.f)), dim3(X_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
+        if (n_edge) hipLaunchKernelGGL((inv_xy_dpp_kernel<NS, true, EXACT, MidT>), dim3(xcd_grid(n_edge * d.f)), dim3(X_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
+        return;
+    }
     if (n_in) hipLaunchKernelGGL((inv_xy_kernel<NS, false, EXACT, MidT, LDS16>), dim3(xcd_grid(n_in * d.f)), dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
     if (n_edge) hipLaunchKernelGGL((inv_xy_kernel<NS, true, EXACT, MidT, LDS16>), dim3(xcd_grid(n_edge * d.f)), dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
 }
