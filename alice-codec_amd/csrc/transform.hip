@@ -719,7 +719,7 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
 // the tile (their far halves are never-read garbage), so lanes 1..12 end up with the same integers as the global pass.
 // Used whenever the packed-i16 tile of inv_xy_kernel<..., LDS16 = true> is not provably safe (e.g. q = 80).
 // ------------------------------------------------------------------------------------------------
-constexpr int X_THREADS = 512;          // 32 rows x 16 lanes in stage B
+constexpr int X_TH = 32, X_THREADS = X_TH * 16;   // stage B: X_TH rows x 16 lanes
 constexpr int X_HO = 56, X_LW = 112;    // tile row: even samples at columns 2 .. 53 (+2 never-read columns each side), odd at 56 + ...
 
 // one inverse/forward lifting pass over the 8 samples of a lane (v[0] even), neighbours by DPP within the 16-lane row
@@ -745,7 +745,7 @@ template <int NS, bool EDGE, bool EXACT, typename MidT>
 __global__ __launch_bounds__(X_THREADS) void inv_xy_dpp_kernel(const MidT* __restrict__ mid, uint8_t* __restrict__ rgb,
                                                                ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
     constexpr int H = NS;
-    constexpr int ER = I_TH + 2 * H;
+    constexpr int ER = X_TH + 2 * H;
     constexpr int EC = I_TW + 2 * H;
     constexpr int ECh = EC / 2;
     __shared__ __attribute__((aligned(16))) int lds[3 * ER * X_LW];
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(X_THREADS) void inv_xy_dpp_kernel(const MidT* __res
         else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
         else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
     }
-    const int gx0 = bx * I_TW, gy0 = by * I_TH;
+    const int gx0 = bx * I_TW, gy0 = by * X_TH;
     const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
     const int gpx0 = (gx0 - H) / 2;
 
@@ -1117,12 +1117,13 @@ static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkD
     const size_t plane = (size_t)d.pw * d.ph;
     dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
     hipLaunchKernelGGL((inv_t_kernel<NS, EXACT, MidT>), gt, dim3(256), 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
-    const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + I_TH - 1) / I_TH;
+    const unsigned th = LDS16 ? (unsigned)I_TH : (unsigned)X_TH;   // tile height of the kernel that will run
+    const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + th - 1) / th;
     const int aligned = (d.w % 4 == 0) && ((((uintptr_t)rgb) & 3u) == 0u);
-    // a tile is interior when the range it reads, [gx0 - 4, gx0 + 96 + 4) x [gy0 - 4, gy0 + 32 + 4), lies inside w x h
+    // a tile is interior when the range it reads, [gx0 - 4, gx0 + 96 + 4) x [gy0 - 4, gy0 + th + 4), lies inside w x h
     // (then inside the padded frame too, and every pixel it writes exists)
     auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * I_TW + I_TW + 4) <= d.w; };
-    auto interior_y = [&](unsigned by) { return by >= 1 && (by * I_TH + I_TH + 4) <= d.h; };
+    auto interior_y = [&](unsigned by) { return by >= 1 && (by * th + th + 4) <= d.h; };
     unsigned ix1 = 1, iy1 = 1;
     while (ix1 < nx && interior_x(ix1)) ++ix1;
     while (iy1 < ny && interior_y(iy1)) ++iy1;
@@ -1148,7 +1149,7 @@ bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wave
     const Coeffs cf = to_coeffs(ls);
     if ((unsigned long long)d.pw * d.ph > (1ull << 30)) return false;   // 32-bit byte offsets inside one frame
     if (d.pw < 6 || d.ph < 6) return false;                             // reflect_idx: one reflection must cover the halo
-    if ((unsigned long long)((d.w + I_TW - 1) / I_TW) * ((d.h + I_TH - 1) / I_TH) * d.f > 0x7FFFFFF0ull) return false;
+    if ((unsigned long long)((d.w + I_TW - 1) / I_TW) * ((d.h + X_TH - 1) / X_TH) * d.f > 0x7FFFFFF0ull) return false;
     // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too);
     // lds16: also after the inverse column pass
     if (ls.n == 4) {
