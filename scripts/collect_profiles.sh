@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): collects the evidence committed under profiles/.
-#   1. rocprofv3 --kernel-trace --stats of the bench command (4 chunks in flight to keep the run short)
+#   1. rocprofv3 --kernel-trace --stats of the bench command itself (default batch, 2 timed steps, oracle check skipped)
 #   2. PMC passes (one counter group per pass, --kernel-trace only) of one 1920x1080x16 chunk for HBM traffic
 #   3. the headline bench line at the default batch
 set -e
@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/final
 rm -rf $OUT
 mkdir -p $OUT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --chunks 4 --steps 2 --warmup 1 --no-verify > $OUT/bench_chunks4_profiled.json 2> $OUT/stats.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 2 --warmup 1 --no-verify > $OUT/bench_profiled.json 2> $OUT/stats.log
 echo "stats done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python scripts/profile_run.py 16 > $OUT/pmc_fetch.log 2>&1
 echo "fetch done"
