@@ -54,6 +54,44 @@ def test_config3_4k64_cdf97_q90_single_chunk(gpu_codec, oracle_mod):
     assert dec.size == rgb.size and np.array_equal(dec, want)
 
 
+def test_config3_eight_4k64_chunks_in_one_batch(gpu_codec, oracle_mod):
+    """The eight 3840x2160x64 chunks of configs[3] as ONE device-resident batch on this GPU (what each of the eight GPUs
+    of that configuration does with its share, and what bench.py times at 1080p): 24 chains side by side, the .alc buffers
+    and the in-place decoded pixels of the first and the last chunk against the oracle, the other six through the header
+    invariants (they are different pictures: the generator is seeded per chunk)."""
+    import torch
+    from alice_codec_amd import multi
+    w, h, f, q, k, n = 3840, 2160, 64, 90, 1, 8
+    px = w * h * f
+    dev = torch.device("cuda", 0)
+    rgb = torch.empty((n, f, h, w, 3), dtype=torch.uint8, device=dev)
+    for i in range(n):
+        rgb[i] = smooth_on_gpu(w, h, f, 9000 + i)
+    bt = gpu_codec.Batch(w, h, f, n, q, gpu_codec.WaveletType(k))
+    st = torch.cuda.current_stream().cuda_stream
+    bt.encode(rgb.data_ptr(), st)
+    sizes = bt.encode_finish()
+    bt.decode(bt.alc_ptr(0), bt.alc_stride, None, st)
+    bt.decode_finish()
+    seen = set()
+    for i in range(n):
+        hdr = multi.DeviceView(bt.alc_ptr(i), 3138).tensor(dev).cpu().numpy().tobytes()
+        assert hdr[:6] == b"ALCC\x01\x01"
+        lens = [int.from_bytes(hdr[18 + 1040 * c: 22 + 1040 * c], "little") for c in range(3)]
+        assert 3138 + sum(lens) == int(sizes[i])
+        for c in range(3):
+            assert int(np.frombuffer(hdr[18 + 1040 * c + 16: 18 + 1040 * (c + 1)], "<u4").astype(np.uint64).sum()) == px
+        seen.add(int(sizes[i]))
+    assert len(seen) == n    # eight different pictures, eight different streams
+    for i in (0, n - 1):
+        host = rgb[i].reshape(-1).cpu().numpy()
+        ref = oracle_mod.encode(host, w, h, f, q, k, three_threads=True)
+        got = multi.DeviceView(bt.alc_ptr(i), int(sizes[i])).tensor(dev).cpu().numpy().tobytes()
+        assert len(got) == len(ref) and hashlib.sha256(got).hexdigest() == hashlib.sha256(ref).hexdigest(), i
+        dec = multi.DeviceView(bt.rgb_ptr(i), px * 3).tensor(dev).cpu().numpy()
+        assert np.array_equal(dec, oracle_mod.decode(ref, three_threads=True)), i
+
+
 def test_config4_8k_row_slabs_world4_vs_oracle():
     """7680x4320 frames, 8 of them, CDF 9/7 q=75, 4 ranks sharing the GPU: 8K-wide tiles and grids, 1080-row slabs with
     4-row halos, histogram all-reduce, symbol rows to the three chain ranks; the sharded .alc and decode against the
