@@ -67,6 +67,27 @@ __device__ __forceinline__ unsigned xcd_logical_block(unsigned total) {
 }
 static inline unsigned xcd_grid(unsigned long long total) { return (unsigned)(((total + 7) / 8) * 8); }
 
+// Which tile this workgroup takes.  An interior launch (EDGE = false) covers the rectangle of tiles [ix0, ix1) x
+// [iy0, iy1) whose halo lies inside the frame; a border launch (EDGE = true) one linear sequence over the four strips
+// around it (top, bottom, left, right).  `frames` frames, XCD-aware order (xcd_logical_block).  False: nothing to do.
+template <bool EDGE>
+__device__ __forceinline__ bool tile_of_block(const TileMap& tm, unsigned frames, int& bx, int& by, int& t) {
+    const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
+    const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
+    const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
+    const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
+    const unsigned l = xcd_logical_block(per_frame * frames);
+    if (l == 0xFFFFFFFFu) return false;
+    t = (int)(l / per_frame);
+    int i = (int)(l % per_frame);
+    if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
+    else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
+    else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
+    else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
+    else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
+    return true;
+}
+
 // Whole-sample symmetric extension of an even-length signal: x[-k] = x[k], x[n-1+k] = x[n-1-k].
 // The reference mirrors one neighbour at the two ends of every lifting step (src/wavelet.rs:186-190,
 // 206-210: the last odd sample predicts from its left neighbour twice, the first even sample updates from
@@ -127,21 +148,7 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
     extern __shared__ int lds[];
     const int tid = threadIdx.x;
     int bx, by, t;
-    {
-        const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
-        const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
-        const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
-        const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
-        const unsigned l = xcd_logical_block(per_frame * d.pf);
-        if (l == 0xFFFFFFFFu) return;
-        t = (int)(l / per_frame);
-        int i = (int)(l % per_frame);
-        if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
-        else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
-        else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
-        else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
-        else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
-    }
+    if (!tile_of_block<EDGE>(tm, (unsigned)d.pf, bx, by, t)) return;
     const int gx0 = bx * F_TW, gy0 = by * F_TH;
     const int pw = d.pw, ph = d.ph;
     const int st = min(t, (int)d.f - 1);
@@ -594,21 +601,7 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
     // interior launch: a rectangle of tiles whose halo lies inside the frame (no mirroring, no clamping, no bounds
     // tests); border launch: one linear sequence over the four strips around it
     int bx, by, t;
-    {
-        const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
-        const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
-        const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
-        const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
-        const unsigned lb = xcd_logical_block(per_frame * d.f);
-        if (lb == 0xFFFFFFFFu) return;
-        t = (int)(lb / per_frame);
-        int i = (int)(lb % per_frame);
-        if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
-        else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
-        else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
-        else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
-        else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
-    }
+    if (!tile_of_block<EDGE>(tm, d.f, bx, by, t)) return;
     const int gx0 = bx * I_TW, gy0 = by * I_TH;
     const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
     const int gpx0 = (gx0 - H) / 2;  // first column pair of the extended tile (may be negative)
@@ -751,21 +744,7 @@ __global__ __launch_bounds__(X_THREADS) void inv_xy_dpp_kernel(const MidT* __res
     __shared__ __attribute__((aligned(16))) int lds[3 * ER * X_LW];
     const int tid = threadIdx.x;
     int bx, by, t;
-    {
-        const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
-        const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
-        const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
-        const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
-        const unsigned lb = xcd_logical_block(per_frame * d.f);
-        if (lb == 0xFFFFFFFFu) return;
-        t = (int)(lb / per_frame);
-        int i = (int)(lb % per_frame);
-        if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
-        else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
-        else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
-        else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
-        else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
-    }
+    if (!tile_of_block<EDGE>(tm, d.f, bx, by, t)) return;
     const int gx0 = bx * I_TW, gy0 = by * X_TH;
     const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
     const int gpx0 = (gx0 - H) / 2;
