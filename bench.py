@@ -33,26 +33,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner) write to
-# file descriptor 1 directly, so keep a private copy of stdout for the result and point fd 1 at stderr.
-_RESULT_OUT = os.fdopen(os.dup(1), "w")
-os.dup2(2, 1)
+# Nothing here touches the GPU or the process's file descriptors at import time: scripts import this module for
+# W / H / F and synth_chunk(); torch and the codec are imported lazily (main() and the helpers that need them).
+_RESULT_OUT = None   # main() points this at a private copy of stdout (see _claim_stdout)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
-import alice_codec_amd as ac  # noqa: E402
-from alice_codec_amd import multi  # noqa: E402
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries (RCCL prints a version banner) write to file
+    descriptor 1 directly, so keep a private copy of stdout for the result and point fd 1 at stderr."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _RESULT_OUT
+
 
 W, H, F = 1920, 1080, 64
 QUALITY = 80
-WAVELET = ac.WaveletType.Cdf97
+WAVELET = None      # ac.WaveletType, set by _mods() / main()
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 
 
-def synth_chunk(dev, idx: int) -> torch.Tensor:
+def _mods():
+    """Import numpy / torch / the codec into this module's globals (first GPU-side use; never at import time)."""
+    global np, torch, dist, ac, multi, WAVELET
+    import numpy as np  # noqa: F811
+    import torch  # noqa: F811
+    import torch.distributed as dist  # noqa: F811
+    import alice_codec_amd as ac  # noqa: F811
+    from alice_codec_amd import multi  # noqa: F811
+    if WAVELET is None:
+        WAVELET = ac.WaveletType.Cdf97
+
+
+def synth_chunk(dev, idx: int):
     """S-smooth: moving sinusoids + integer noise in [-4, 4], generated on the device."""
+    _mods()
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + idx)
     t = torch.arange(F, device=dev, dtype=torch.float32).view(F, 1, 1, 1)
@@ -119,7 +135,7 @@ def verify_and_baseline(first, last, frames: int) -> dict:
     }
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -134,16 +150,103 @@ def main() -> None:
                     help="decode into a caller-owned RGB buffer instead of the batch's own storage (one more RGB-sized buffer per chunk)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the batch and the CPU baseline (the line then does not say bit-exact)")
-    args = ap.parse_args()
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the drop-in host-call measurement (T host threads through alice_codec_encode64 / decode64)")
+    return ap.parse_args(argv)
 
+
+# ---- N ranks from one command ------------------------------------------------------------------------------------
+# `python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) starts the N ranks ITSELF, as child processes,
+# before anything in this process has touched the GPU; under torchrun (WORLD_SIZE set) the process is one rank.  Any
+# disagreement between --gpus and the environment is an error, never a silent single-GPU number.
+
+def plan_ranks(n_gpus: int, argv: list, env: dict, port: int, python: str = sys.executable) -> list:
+    """The child processes of a self-spawned N-rank run: [(command line, environment)], rank i on GPU i.  Pure."""
+    plan = []
+    for r in range(n_gpus):
+        e = dict(env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ALICE_BENCH_SPAWNED": "1"})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        plan.append(([python, os.path.abspath(__file__)] + list(argv), e))
+    return plan
+
+
+def check_launch(n_gpus: int, env: dict, visible_devices) -> str:
+    """What this invocation is: "rank" (run as one rank of the world the environment describes), "spawn" (start
+    n_gpus ranks), or an error message (then the process must exit non-zero).  Pure; visible_devices may be None
+    (not counted yet)."""
+    ws = env.get("WORLD_SIZE")
+    if n_gpus < 1:
+        return f"error: --gpus {n_gpus}"
+    if ws is not None:
+        if int(ws) != n_gpus:
+            return (f"error: --gpus {n_gpus} but the launcher set WORLD_SIZE={ws}: refusing to report a "
+                    f"{ws}-rank number as n_gpus={n_gpus}")
+        return "rank"
+    if n_gpus == 1:
+        return "rank"
+    if visible_devices is not None and visible_devices < n_gpus:
+        return (f"error: --gpus {n_gpus} but only {visible_devices} GPU(s) are visible on this node: not running a "
+                f"smaller world under that label")
+    return "spawn"
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv) -> int:
+    """Start the N ranks, relay rank 0's JSON line (the children inherit this process's stdout; only rank 0 writes to
+    it), wait for all, return the first non-zero exit code (the other ranks are then terminated by PID)."""
+    plan = plan_ranks(args.gpus, argv, dict(os.environ), _free_port())
+    if os.environ.get("ALICE_BENCH_SPAWN_DRYRUN") == "1":   # tests: show the plan, start nothing
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+        print(json.dumps([{"cmd": c, "env": {k: e.get(k) for k in keys}} for c, e in plan]))
+        return 0
+    procs = [subprocess.Popen(c, env=e) for c, e in plan]
+    print(f"[bench] started {len(procs)} ranks: pids {[p.pid for p in procs]}", file=sys.stderr)
+    rc = 0
+    live = set(range(len(procs)))
+    while live:
+        for i in sorted(live):
+            r = procs[i].poll()
+            if r is None:
+                continue
+            live.discard(i)
+            if r != 0 and rc == 0:
+                rc = r
+                print(f"[bench] rank {i} exited with {r}: stopping the other ranks", file=sys.stderr)
+                for j in live:
+                    procs[j].terminate()
+        time.sleep(0.2)
+    return rc
+
+
+def main(argv=None) -> None:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    n_visible = None
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and os.environ.get("ALICE_BENCH_SPAWN_DRYRUN") != "1":
+        import torch as _t
+        n_visible = _t.cuda.device_count()      # counting devices does not initialise the GPU on this image
+    what = check_launch(args.gpus, os.environ, n_visible)
+    if what.startswith("error"):
+        raise SystemExit("bench.py: " + what)
+    if what == "spawn":
+        raise SystemExit(spawn_ranks(args, argv))
+
+    _claim_stdout()
+    _mods()
     global QUALITY, WAVELET
     QUALITY = args.quality
     WAVELET = {"cdf97": ac.WaveletType.Cdf97, "cdf53": ac.WaveletType.Cdf53, "haar": ac.WaveletType.Haar}[args.wavelet]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -156,6 +259,17 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus and not os.environ.get("ALICE_BENCH_FORCE_DIST"):
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    # who is in the job, as the ranks themselves see it (answers "did RCCL see N ranks" from the record)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "hbm_gb": round(props.total_memory / 1e9, 1)}
+    if use_dist:
+        ranks_seen = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_seen, me)
+    else:
+        ranks_seen = [me]
 
     px_chunk = W * H * F
     stream = torch.cuda.current_stream().cuda_stream
@@ -303,6 +417,9 @@ def main() -> None:
                        "chunks_per_gpu": B, "wavelet": args.wavelet, "quality": QUALITY, "sizing": sizing,
                        "hbm_free_after_timed_steps_gb": round(free_b / 1e9, 1), "hbm_total_gb": round(total_b / 1e9, 1),
                        "parallelism": f"chunk-parallel x{world}" + (" + RCCL point-to-point stream of the .alc blobs to rank 0 (receive ring -> pinned host)" if world > 1 else "")},
+            "ranks": {"world_size_seen_by_process_group": dist.get_world_size() if use_dist else 1, "devices": ranks_seen,
+                      "launched_by": "bench.py itself (child processes)" if os.environ.get("ALICE_BENCH_SPAWNED") else
+                                     ("a launcher (WORLD_SIZE was set)" if "WORLD_SIZE" in os.environ else "single process")},
             "batch_bit_exact": bit_exact,
             "encode_mpix_s": round(world * B * px_chunk / ((ms["forward_transform"] + ms["rans_table"] + ms["rans_encode"] + ms["assemble"]) / 1e3) / 1e6, 2),
             "decode_mpix_s": round(world * B * px_chunk / ((ms["rans_decode"] + ms["inverse_transform"]) / 1e3) / 1e6, 2),
