@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalice_codec.so")
+# ALICE_CODEC_LIB: developer override (A/B runs of two builds of the library); the product loads the in-tree build
+LIB_PATH = os.environ.get("ALICE_CODEC_LIB") or os.path.join(_HERE, "libalice_codec.so")
 
 VERSION = "0.1.2"
 DEFAULT_CHUNK_SIZE = 64  # reference src/lib.rs:110
@@ -120,8 +121,27 @@ def load_library() -> C.CDLL:
         "alice_codec_device_count": (C.c_int, []),
         "alice_codec_set_device": (C.c_int, [C.c_int]),
         "alice_codec_trim": (None, []),
+        "alice_codec_freq_table_from_histogram_n": (C.c_int, [_u32p, C.c_uint32, _u16p, _u16p]),
+        "alice_codec_rans_encoder_new": (vp, []),
+        "alice_codec_rans_encoder_destroy": (None, [vp]),
+        "alice_codec_rans_encoder_encode": (C.c_int, [vp, C.c_uint16, C.c_uint16]),
+        "alice_codec_rans_encoder_encode_symbols": (C.c_int, [vp, _u8p, C.c_uint64, _u16p, _u16p]),
+        "alice_codec_rans_encoder_state": (C.c_uint32, [vp]),
+        "alice_codec_rans_encoder_finish": (vp, [vp, _u64p]),
+        "alice_codec_rans_decoder_new": (vp, [_u8p, C.c_uint64]),
+        "alice_codec_rans_decoder_destroy": (None, [vp]),
+        "alice_codec_rans_decoder_decode_n": (C.c_int, [vp, C.c_uint64, _u16p, _u16p, _u8p]),
+        "alice_codec_rans_decoder_is_empty": (C.c_int, [vp]),
+        "alice_codec_rans_decoder_state": (C.c_uint32, [vp]),
+        "alice_codec_rans_decoder_position": (C.c_uint64, [vp]),
+        "alice_codec_quantize_subband": (C.c_int, [C.c_int32, C.c_int32, _i32p, C.c_uint64, _i32p, C.c_uint64]),
+        "alice_codec_dequantize_subband": (C.c_int, [C.c_int32, _i32p, C.c_uint64, _i32p, C.c_uint64]),
         "alice_codec_test_force_first_cap": (None, [C.c_uint64]),
         "alice_codec_test_last_decode_stats": (None, [_u32p]),
+        "alice_codec_test_chain_occupancy": (C.c_int, [_u32p]),
+        "alice_codec_test_set_tuning": (None, [C.c_long, C.c_long, C.c_long]),
+        "alice_codec_test_transform_ms": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
+                                                    C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_float), vp]),
         "alice_codec_encoder_create_ex": (vp, [C.c_uint8, C.c_uint8]),
         "alice_codec_encoder_quality": (C.c_uint8, [vp]),
         "alice_codec_encoder_wavelet": (C.c_uint8, [vp]),
@@ -134,6 +154,10 @@ def load_library() -> C.CDLL:
         "alice_codec_data_free64": (None, [vp, C.c_uint64]),
         "alice_codec_encode_many": (C.c_int, [vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
         "alice_codec_decode_many": (C.c_int, [C.POINTER(vp), C.c_uint32, _u8p, C.c_uint64]),
+        "alice_codec_many_devices_plan": (C.c_int, [C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_int)]),
+        "alice_codec_encode_many_devices": (C.c_int, [vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                      C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]),
+        "alice_codec_decode_many_devices": (C.c_int, [C.POINTER(vp), C.c_uint32, C.POINTER(C.c_int), C.c_uint32, _u8p, C.c_uint64]),
         "alice_codec_batch_create": (vp, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8]),
         "alice_codec_batch_destroy": (None, [vp]),
         "alice_codec_batch_encode": (C.c_int, [vp, vp, vp]),
@@ -344,9 +368,18 @@ class FrameEncoder:
         return EncodedChunk(h)
 
 
-def encode_many(encoder: "FrameEncoder", rgb_chunks, width: int, height: int, frames: int) -> list:
+def plan_devices(n_chunks: int, devices) -> list:
+    """Which device each chunk of a multi-device call runs on: chunk k -> devices[k mod len(devices)] (no GPU touched)."""
+    devs = (C.c_int * len(devices))(*[int(x) for x in devices])
+    out = (C.c_int * max(n_chunks, 1))()
+    _check(load_library().alice_codec_many_devices_plan(n_chunks, devs, len(devices), out))
+    return list(out)[:n_chunks]
+
+
+def encode_many(encoder: "FrameEncoder", rgb_chunks, width: int, height: int, frames: int, devices=None) -> list:
     """n equal-shaped chunks (array of shape [n, frames*height*width*3] or a flat buffer) in one call: all their
-    entropy chains run side by side.  Returns n EncodedChunk, identical to n FrameEncoder.encode calls."""
+    entropy chains run side by side.  Returns n EncodedChunk, identical to n FrameEncoder.encode calls.
+    devices: a list of GPU indices -- chunk k runs on devices[k mod len(devices)], one host thread per entry."""
     lib = load_library()
     r = _as_u8(rgb_chunks)
     per = width * height * frames * 3
@@ -354,12 +387,16 @@ def encode_many(encoder: "FrameEncoder", rgb_chunks, width: int, height: int, fr
         raise CodecError(1, "buffer is not a whole number of chunks")
     n = r.size // per
     handles = (C.c_void_p * n)()
-    _check(lib.alice_codec_encode_many(encoder._h, _p(r, _u8p), r.size, width, height, frames, n, handles))
+    if devices is None:
+        _check(lib.alice_codec_encode_many(encoder._h, _p(r, _u8p), r.size, width, height, frames, n, handles))
+    else:
+        devs = (C.c_int * len(devices))(*[int(x) for x in devices])
+        _check(lib.alice_codec_encode_many_devices(encoder._h, _p(r, _u8p), r.size, width, height, frames, n, devs, len(devices), handles))
     return [EncodedChunk(h) for h in handles]
 
 
-def decode_many(chunks) -> np.ndarray:
-    """n equal-shaped chunks -> uint8 array [n, frames*height*width*3]"""
+def decode_many(chunks, devices=None) -> np.ndarray:
+    """n equal-shaped chunks -> uint8 array [n, frames*height*width*3]; devices as in encode_many"""
     lib = load_library()
     n = len(chunks)
     if n == 0:
@@ -368,7 +405,11 @@ def decode_many(chunks) -> np.ndarray:
     out = np.zeros((n, per), np.uint8)
     handles = (C.c_void_p * n)(*[c._h for c in chunks])
     z = C.cast(C.c_char_p(b""), _u8p)
-    _check(lib.alice_codec_decode_many(handles, n, _p(out, _u8p) if out.size else z, out.size))
+    if devices is None:
+        _check(lib.alice_codec_decode_many(handles, n, _p(out, _u8p) if out.size else z, out.size))
+    else:
+        devs = (C.c_int * len(devices))(*[int(x) for x in devices])
+        _check(lib.alice_codec_decode_many_devices(handles, n, devs, len(devices), _p(out, _u8p) if out.size else z, out.size))
     return out
 
 
@@ -545,6 +586,22 @@ class Quantizer:
         return int(self.dequantize_buffer([q])[0])
 
 
+def quantize_subband(coeffs, quantizer: Quantizer, out_len: int | None = None) -> np.ndarray:
+    """reference src/quant.rs:518-524"""
+    v = np.ascontiguousarray(coeffs, np.int32).reshape(-1)
+    out = np.zeros(v.size if out_len is None else out_len, np.int32)
+    _check(load_library().alice_codec_quantize_subband(quantizer.step, quantizer.dead_zone, _p(v, _i32p), v.size, _p(out, _i32p), out.size))
+    return out
+
+
+def dequantize_subband(coeffs, quantizer: Quantizer, out_len: int | None = None) -> np.ndarray:
+    """reference src/quant.rs:531-537"""
+    v = np.ascontiguousarray(coeffs, np.int32).reshape(-1)
+    out = np.zeros(v.size if out_len is None else out_len, np.int32)
+    _check(load_library().alice_codec_dequantize_subband(quantizer.step, _p(v, _i32p), v.size, _p(out, _i32p), out.size))
+    return out
+
+
 class SubBand3D(enum.IntEnum):  # reference src/lib.rs:115-158
     LLL = 0
     LLH = 1
@@ -661,50 +718,78 @@ def build_histogram(symbols) -> np.ndarray:
 # ---------------------------------------------------------------------------------------------
 
 class FrequencyTable:
-    """reference src/rans.rs:85-219 over the 256-symbol alphabet of the pipeline."""
+    """reference src/rans.rs:85-219.  n symbols, 1 <= n <= 256 (the coders address symbols as u8); the arrays always
+    hold 256 entries, those from n on are (0, 0)."""
 
-    def __init__(self, cum_freq: np.ndarray, freq: np.ndarray):
+    def __init__(self, cum_freq: np.ndarray, freq: np.ndarray, n_symbols: int = 256):
         self.cum_freq = np.ascontiguousarray(cum_freq, np.uint16)
         self.freq = np.ascontiguousarray(freq, np.uint16)
+        self._n = int(n_symbols)
 
     @classmethod
     def from_histogram(cls, histogram) -> "FrequencyTable":
         h = np.ascontiguousarray(histogram, np.uint32).reshape(-1)
-        if h.size != 256:
-            raise ValueError("the GPU path supports the pipeline's 256-bin histograms")
         cum = np.zeros(256, np.uint16); fr = np.zeros(256, np.uint16)
-        _check(load_library().alice_codec_freq_table_from_histogram(_p(h, _u32p), _p(cum, _u16p), _p(fr, _u16p)))
-        return cls(cum, fr)
+        z = C.cast(C.c_char_p(b""), _u32p)
+        _check(load_library().alice_codec_freq_table_from_histogram_n(_p(h, _u32p) if h.size else z, h.size, _p(cum, _u16p), _p(fr, _u16p)))
+        return cls(cum, fr, h.size)
 
     @classmethod
     def uniform(cls, n_symbols: int = 256) -> "FrequencyTable":
-        if n_symbols != 256:
-            raise ValueError("the GPU path supports 256 symbols")
-        return cls.from_histogram(np.zeros(256, np.uint32))  # total == 0 -> uniform (src/rans.rs:106-109)
+        return cls.from_histogram(np.zeros(n_symbols, np.uint32))  # total == 0 -> uniform(n) (src/rans.rs:106-109)
 
-    def __len__(self): return 256
+    def get_symbol(self, sym: int) -> "RansSymbol":               # src/rans.rs:194
+        if not 0 <= sym < self._n:
+            raise IndexError("symbol index out of range")          # the reference panics
+        return RansSymbol(int(self.cum_freq[sym]), int(self.freq[sym]))
+
+    def __len__(self): return self._n
+
+    def is_empty(self) -> bool: return self._n == 0
+
+
+class RansSymbol:
+    """reference src/rans.rs:59-72"""
+
+    def __init__(self, cum_freq: int, freq: int):
+        self.cum_freq = int(cum_freq) & 0xFFFF
+        self.freq = int(freq) & 0xFFFF
 
 
 class RansEncoder:
-    """reference src/rans.rs:238-309: encode_symbols (reverse order) + finish."""
+    """reference src/rans.rs:238-309: an encoder object; encode / encode_symbols any number of times, then finish."""
 
-    def __init__(self): self._pending = None
+    def __init__(self):
+        lib = load_library()
+        self._h = lib.alice_codec_rans_encoder_new()
+        if not self._h:
+            _raise_last()
 
     @classmethod
-    def with_capacity(cls, capacity: int): return cls()
+    def with_capacity(cls, capacity: int): return cls()            # the capacity is a hint in the reference too
 
-    def encode_symbols(self, symbols, table: FrequencyTable) -> None:
-        if self._pending is not None:
-            raise ValueError("one encode_symbols call per encoder on the GPU path")
-        self._pending = (_as_u8(symbols).copy(), table)
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().alice_codec_rans_encoder_destroy(self._h)
+            self._h = None
 
-    def finish(self) -> bytes:
+    def encode(self, sym: RansSymbol) -> None:                     # :269-285
+        _check(load_library().alice_codec_rans_encoder_encode(self._h, sym.cum_freq, sym.freq))
+
+    def encode_symbols(self, symbols, table: FrequencyTable) -> None:   # :288-294
+        s = _as_u8(symbols)
+        if s.size:
+            _check(load_library().alice_codec_rans_encoder_encode_symbols(self._h, _p(s, _u8p), s.size, _p(table.cum_freq, _u16p),
+                                                                          _p(table.freq, _u16p)))
+
+    @property
+    def state(self) -> int: return int(load_library().alice_codec_rans_encoder_state(self._h))
+
+    def finish(self) -> bytes:                                     # :298-308, consumes the encoder
         lib = load_library()
-        sym, table = self._pending if self._pending is not None else (np.zeros(0, np.uint8), FrequencyTable.uniform())
         n = C.c_uint64()
-        z = C.cast(C.c_char_p(b""), _u8p)
-        p = lib.alice_codec_rans_encode(_p(sym, _u8p) if sym.size else z, sym.size, _p(table.cum_freq, _u16p),
-                                        _p(table.freq, _u16p), C.byref(n))
+        h, self._h = self._h, None
+        p = lib.alice_codec_rans_encoder_finish(h, C.byref(n))
         if not p:
             _raise_last()
         try:
@@ -714,17 +799,38 @@ class RansEncoder:
 
 
 class RansDecoder:
-    """reference src/rans.rs:321-389: new + decode_n."""
+    """reference src/rans.rs:321-389: a decoder object; decode / decode_n continue from the current position."""
 
-    def __init__(self, data): self._data = _as_u8(data).copy()
+    def __init__(self, data):
+        d = _as_u8(data)
+        z = C.cast(C.c_char_p(b""), _u8p)
+        self._h = load_library().alice_codec_rans_decoder_new(_p(d, _u8p) if d.size else z, d.size)
+        if not self._h:
+            _raise_last()
 
-    def decode_n(self, n: int, table: FrequencyTable) -> np.ndarray:
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().alice_codec_rans_decoder_destroy(self._h)
+            self._h = None
+
+    def decode_n(self, n: int, table: FrequencyTable) -> np.ndarray:    # :375-381
         out = np.zeros(n, np.uint8)
         z = C.cast(C.c_char_p(b""), _u8p)
-        _check(load_library().alice_codec_rans_decode(_p(self._data, _u8p) if self._data.size else z, self._data.size,
-                                                      _p(table.cum_freq, _u16p), _p(table.freq, _u16p), n,
-                                                      _p(out, _u8p) if n else z))
+        _check(load_library().alice_codec_rans_decoder_decode_n(self._h, n, _p(table.cum_freq, _u16p), _p(table.freq, _u16p),
+                                                                _p(out, _u8p) if n else z))
         return out
+
+    def decode(self, table: FrequencyTable) -> int:                # :351-371
+        return int(self.decode_n(1, table)[0])
+
+    def is_empty(self) -> bool:                                    # :385-389
+        return bool(load_library().alice_codec_rans_decoder_is_empty(self._h))
+
+    @property
+    def state(self) -> int: return int(load_library().alice_codec_rans_decoder_state(self._h))
+
+    @property
+    def position(self) -> int: return int(load_library().alice_codec_rans_decoder_position(self._h))
 
 
 class InterleavedRansEncoder:

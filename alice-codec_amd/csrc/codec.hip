@@ -22,9 +22,11 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/alice_codec.h"
+#include "../../include/alice_codec_test.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -226,6 +228,11 @@ struct EncodedChunk {             // reference src/pipeline.rs:172-185
 struct FrameEncoder { uint8_t quality; uint8_t wavelet; };
 struct Wavelet1D { int kind; };
 struct FastQuantizer { uint64_t reciprocal; uint32_t shift; int32_t step; int32_t dead_zone; };
+// RansEncoder (src/rans.rs:238-242: state + output vector).  Every call emits its bytes back to front, so a call's
+// segment reads front to back in the order finish() wants; finish() = state bytes, then the segments newest first.
+struct AliceRansEncoder { uint32_t state = alice::kRansL; std::vector<std::vector<uint8_t>> segments; uint64_t bytes = 0; };
+// RansDecoder (src/rans.rs:321-326: state, input, pos)
+struct AliceRansDecoder { std::vector<uint8_t> input; uint32_t state = 0; uint64_t pos = 0; bool started = false; };
 
 namespace {
 
@@ -331,16 +338,23 @@ InverseBounds inverse_bounds(int wavelet, const int32_t step[3]) {
     return r;
 }
 
+// (re)allocates only when the buffer is too small; the caller guarantees nothing in flight still uses it
+int ensure_bytes(DevBuf& b, size_t bytes) {
+    if (b.p && b.n >= bytes) return kOk;
+    return b.alloc(bytes);
+}
+
 struct EncodeWork {
     ChunkDims d{};
     int n_chunks = 0;
     uint64_t cap[3] = {0, 0, 0}, alc_stride = 0;   // stream regions of the Y, Co, Cg chains of a chunk
-    DevBuf mid, tmp, sym, hist, tables, results, alc, sizes, planes;
+    DevBuf scratch;   // band slots of the tile path (forward_scratch_bytes; a batch sizes it for its decode side too)
+    DevBuf gen, tmp, sym, hist, tables, results, alc, sizes, planes;   // gen / tmp / planes: generic path only
 };
 
-int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks) {
+int encode_work_alloc(EncodeWork& w, const ChunkDims& d, int n_chunks, size_t scratch_bytes = 0) {
     w.d = d; w.n_chunks = n_chunks; w.cap[0] = w.cap[1] = w.cap[2] = 0; w.alc_stride = 0;
-    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
+    if (transform_tiles_eligible(d)) TRY(w.scratch.alloc(std::max(forward_scratch_bytes(d), scratch_bytes)));
     TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded));
     TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
     TRY(w.tables.alloc((size_t)n_chunks * 3 * sizeof(RansTable)));
@@ -395,9 +409,10 @@ int forward_generic(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32
                     uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
     if (!w.planes.p) TRY(w.planes.alloc(3 * d.n_pixels * sizeof(int16_t)));
     if (!w.tmp.p) TRY(w.tmp.alloc(d.padded * sizeof(int32_t)));
+    if (!w.gen.p) TRY(w.gen.alloc(2 * d.padded * sizeof(int32_t)));
     int16_t* pl = w.planes.as<int16_t>();
     launch_rgb_to_ycocg(d_rgb, d.n_pixels, pl, pl + d.n_pixels, pl + 2 * d.n_pixels, st);
-    int32_t* vol = w.mid.as<int32_t>();
+    int32_t* vol = w.gen.as<int32_t>();
     int32_t* qb = vol + d.padded;
     const uint64_t W = d.pw, H = d.ph, D = d.pf;
     for (int c = 0; c < 3; ++c) {
@@ -412,7 +427,7 @@ int forward_generic(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32
     return kOk;
 }
 
-std::atomic<uint64_t> g_test_first_cap{0};
+thread_local uint64_t tl_test_first_cap = 0;   // alice_codec_test_force_first_cap
 thread_local uint32_t tl_dec_stats[4] = {0, 0, 0, 0};   // last single-chain decode of this thread: fast tiles, exact tiles, path mask, bytes consumed
 void note_decode_stats(const RansResult& r) {
     tl_dec_stats[0] = r.fast_tiles; tl_dec_stats[1] = r.slow_tiles; tl_dec_stats[2] = r.paths;
@@ -441,12 +456,20 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
     const int B = w.n_chunks;
     HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)B * 3 * 256 * sizeof(uint32_t), st));
     if (evs) HIP_TRY(hipEventRecord(evs->ev[0], st));
-    for (int b = 0; b < B; ++b) {
-        const uint8_t* rgb = d_rgb + (size_t)b * d.n_pixels * 3;
-        uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
-        uint32_t* hist = w.hist.as<uint32_t>() + (size_t)b * 3 * 256;
-        if (!launch_forward_transform(rgb, d, wavelet, step, w.mid.as<int32_t>(), sym, hist, st))
-            TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
+    {
+        // chunk after chunk through one pipe: the temporal pass of a chunk's last band shares a launch with the tile
+        // pass of the next chunk's first band
+        ForwardPipe pipe;
+        for (int b = 0; b < B; ++b) {
+            const uint8_t* rgb = d_rgb + (size_t)b * d.n_pixels * 3;
+            uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
+            uint32_t* hist = w.hist.as<uint32_t>() + (size_t)b * 3 * 256;
+            if (!w.scratch.p || !pipe.enqueue(rgb, d, wavelet, step, w.scratch.p, sym, hist, st)) {
+                pipe.flush(st);
+                TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
+            }
+        }
+        pipe.flush(st);
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[1], st));
     uint64_t cap[3] = {cap_override, cap_override, cap_override};
@@ -459,7 +482,7 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
         for (int c = 0; c < 3; ++c) cap[c] = std::min(round_up(cap[c], 256), worst_cap(d));
         // test-only override (alice_codec_test_force_first_cap): pretend the estimate was far too small, to exercise
         // the overflow-and-retry path
-        if (const uint64_t forced = g_test_first_cap.load(std::memory_order_relaxed)) cap[0] = cap[1] = cap[2] = forced;
+        if (const uint64_t forced = tl_test_first_cap) cap[0] = cap[1] = cap[2] = forced;
     }
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
@@ -499,17 +522,16 @@ int encode_collect(EncodeWork& w, hipStream_t st, std::vector<RansResult>& res) 
 struct DecodeWork {
     ChunkDims d{};
     int n_chunks = 0;
-    DevBuf mid, tmp, sym, hist, tables, descs, results, planes, vol;
+    DevBuf scratch_own, gen, tmp, sym, hist, tables, descs, results, planes;
     uint8_t* sym_ptr = nullptr;   // decoded symbols: own buffer, or one lent by the caller
-    int32_t* mid_ptr = nullptr;
+    DevBuf* scratch = nullptr;    // band slots of the tile path: own buffer, or the one a batch shares with its encode side
 };
 
-// sym_ext / mid_ext: buffers the caller lends (a batch reuses its encode-side symbol and scratch buffers,
+// sym_ext / scratch_ext: buffers the caller lends (a batch reuses its encode-side symbol and scratch buffers,
 // which are dead once the encode has finished)
-int decode_work_alloc(DecodeWork& w, const ChunkDims& d, int n_chunks, uint8_t* sym_ext = nullptr, int32_t* mid_ext = nullptr) {
+int decode_work_alloc(DecodeWork& w, const ChunkDims& d, int n_chunks, uint8_t* sym_ext = nullptr, DevBuf* scratch_ext = nullptr) {
     w.d = d; w.n_chunks = n_chunks;
-    if (mid_ext) w.mid_ptr = mid_ext;
-    else { TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t))); w.mid_ptr = w.mid.as<int32_t>(); }
+    w.scratch = scratch_ext ? scratch_ext : &w.scratch_own;
     if (sym_ext) w.sym_ptr = sym_ext;
     else { TRY(w.sym.alloc((size_t)n_chunks * 3 * d.padded)); w.sym_ptr = w.sym.as<uint8_t>(); }
     TRY(w.hist.alloc((size_t)n_chunks * 3 * 256 * sizeof(uint32_t)));
@@ -523,8 +545,9 @@ int inverse_generic(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const
                     uint8_t* d_rgb, hipStream_t st) {
     if (!w.planes.p) TRY(w.planes.alloc(3 * d.n_pixels * sizeof(int16_t)));
     if (!w.tmp.p) TRY(w.tmp.alloc(d.padded * sizeof(int32_t)));
+    if (!w.gen.p) TRY(w.gen.alloc(2 * d.padded * sizeof(int32_t)));
     int16_t* pl = w.planes.as<int16_t>();
-    int32_t* qb = w.mid_ptr;
+    int32_t* qb = w.gen.as<int32_t>();
     int32_t* vol = qb + d.padded;
     const uint64_t W = d.pw, H = d.ph, D = d.pf;
     for (int c = 0; c < 3; ++c) {
@@ -539,12 +562,27 @@ int inverse_generic(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const
     return kOk;
 }
 
-// headers[b]: parsed chunk headers (validated); d_payload[b]: device pointer to chunk b's payload
-// rgb_stride: bytes between the outputs of consecutive chunks (0 = packed, n_pixels * 3)
+// headers[b]: parsed chunk headers (validated); d_payload[b]: device pointer to chunk b's payload;
+// d_rgb[b]: where chunk b's pixels go
 int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<const uint8_t*>& d_payload,
-                  DecodeWork& w, uint8_t* d_rgb_out, hipStream_t st, StageEvents* evs, uint64_t rgb_stride = 0) {
+                  DecodeWork& w, const std::vector<uint8_t*>& d_rgb, hipStream_t st, StageEvents* evs) {
     const ChunkDims& d = w.d;
     const int B = w.n_chunks;
+    if (transform_tiles_eligible(d)) {
+        // band slots: i16 when every chunk's bound allows it, else i32 (sized before anything is queued: the chunks of
+        // a batch share the ring, and growing it must not wait for the chains)
+        bool all16 = true;
+        for (int b = 0; b < B; ++b) {
+            int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
+            const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
+            all16 = all16 && ib.fast && ib.mid16;
+        }
+        const size_t need = inverse_scratch_bytes(d, all16);
+        if (!w.scratch->p || w.scratch->n < need) {
+            HIP_TRY(hipStreamSynchronize(st));   // an earlier call's tail may still use the old ring
+            TRY(ensure_bytes(*w.scratch, need));
+        }
+    }
     std::vector<uint32_t> hist((size_t)B * 3 * 256);
     std::vector<RansDecodeDesc> descs((size_t)B * 3);
     for (int b = 0; b < B; ++b) {
@@ -568,13 +606,19 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
     launch_rans_decode(w.descs.as<RansDecodeDesc>(), w.results.as<RansResult>(), 3 * B, st);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[6], st));
-    for (int b = 0; b < B; ++b) {
-        int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
-        const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
-        const uint8_t* sym = w.sym_ptr + (size_t)b * 3 * d.padded;
-        uint8_t* rgb = d_rgb_out + (size_t)b * (rgb_stride ? rgb_stride : d.n_pixels * 3);
-        if (!launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.mid_ptr, rgb, st))
-            TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, rgb, st));
+    {
+        const bool tiles = transform_tiles_eligible(d) && w.scratch->p;
+        InversePipe pipe;
+        for (int b = 0; b < B; ++b) {
+            int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
+            const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
+            const uint8_t* sym = w.sym_ptr + (size_t)b * 3 * d.padded;
+            if (!tiles || !pipe.enqueue(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.scratch->p, d_rgb[b], st)) {
+                pipe.flush(st);
+                TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, d_rgb[b], st));
+            }
+        }
+        pipe.flush(st);
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[7], st));
     HIP_TRY(hipGetLastError());
@@ -676,7 +720,7 @@ int decode_host(const EncodedChunk& c, std::vector<uint8_t>& rgb) {
     hdrs[0].width = c.width; hdrs[0].height = c.height; hdrs[0].frames = c.frames; hdrs[0].wavelet = c.wavelet;
     for (int k = 0; k < 3; ++k) hdrs[0].ch[k] = c.ch[k];
     std::vector<const uint8_t*> pay(1, d_payload.as<uint8_t>());
-    TRY(decode_launch(hdrs, pay, w, d_rgb.as<uint8_t>(), st, nullptr));
+    TRY(decode_launch(hdrs, pay, w, std::vector<uint8_t*>(1, d_rgb.as<uint8_t>()), st, nullptr));
     TRY(decode_collect(w, st));
     rgb.resize(d.n_pixels * 3);
     HIP_TRY(hipMemcpyAsync(rgb.data(), d_rgb.p, rgb.size(), hipMemcpyDeviceToHost, st));
@@ -755,6 +799,8 @@ struct AliceBatch {
     int device = 0;
     EncodeWork enc;
     DecodeWork dec;
+    DevBuf spare;             // in-place decode: the pixels of chunk 0 (chunk i > 0 lands on the symbols of chunk i - 1)
+    std::vector<uint8_t*> rgb_dst;   // where the last decode put each chunk's pixels
     bool dec_ready = false;
     StageEvents evs;
     hipStream_t enc_stream = nullptr, dec_stream = nullptr;
@@ -909,7 +955,7 @@ int alice_codec_set_device(int device) {
     return ensure_device();
 }
 void alice_codec_trim(void) { pool().trim(); }
-void alice_codec_test_force_first_cap(uint64_t cap) { g_test_first_cap.store(cap, std::memory_order_relaxed); }
+void alice_codec_test_force_first_cap(uint64_t cap) { tl_test_first_cap = cap; }
 
 FrameEncoder* alice_codec_encoder_create_ex(uint8_t quality, uint8_t wavelet_type) {
     clear_error();
@@ -934,7 +980,8 @@ AliceBatch* alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t f
     AliceBatch* b = new (std::nothrow) AliceBatch();
     if (!b) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
     b->d = d; b->n_chunks = n_chunks; b->quality = quality; b->wavelet = wavelet_type; b->device = tl_device;
-    if (encode_work_alloc(b->enc, d, (int)n_chunks) != kOk || b->evs.init() != kOk) { delete b; return nullptr; }
+    // one ring of band slots serves the encode and the decode side (i16 both ways for every quality the bound covers)
+    if (encode_work_alloc(b->enc, d, (int)n_chunks, inverse_scratch_bytes(d, true)) != kOk || b->evs.init() != kOk) { delete b; return nullptr; }
     return b;
 }
 void alice_codec_batch_destroy(AliceBatch* b) {
@@ -1013,7 +1060,7 @@ int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stri
     b->dec_stream = st;
     b->dec_timed = false;
     if (!b->dec_ready) {
-        TRY(decode_work_alloc(b->dec, b->d, (int)b->n_chunks, b->enc.sym.as<uint8_t>(), b->enc.mid.as<int32_t>()));
+        TRY(decode_work_alloc(b->dec, b->d, (int)b->n_chunks, b->enc.sym.as<uint8_t>(), &b->enc.scratch));
         b->dec_ready = true;
     }
     // headers: one strided device-to-host copy, then validation on the host
@@ -1032,15 +1079,23 @@ int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stri
         TRY(validate_for_decode(headers[i], &dd, payload));
         pay[i] = (const uint8_t*)d_alc + (size_t)i * alc_stride + kAlcHeaderBytes;
     }
-    // d_rgb_out == NULL: every chunk is reconstructed over its own (by then consumed) symbols, see
-    // alice_codec_batch_rgb_ptr; the temporal pass of chunk i is the last reader of those symbols and runs
-    // before the tile pass that writes the pixels.
-    if (!d_rgb_out) return decode_launch(headers, pay, b->dec, b->dec.sym_ptr, st, &b->evs, 3 * b->d.padded);
-    return decode_launch(headers, pay, b->dec, (uint8_t*)d_rgb_out, st, &b->evs);
+    // d_rgb_out == NULL: the batch keeps the pixels in its own storage (alice_codec_batch_rgb_ptr).  The launches work band
+    // by band, so the tile pass of a chunk's first band writes pixels while the temporal pass of its later bands still
+    // reads symbols: the pixels of chunk i therefore land on the symbols of chunk i - 1, whose last reader (its own
+    // temporal pass) finished launches ago, and chunk 0 gets a buffer of its own.
+    b->rgb_dst.assign(b->n_chunks, nullptr);
+    if (!d_rgb_out) {
+        if (!b->spare.p) TRY(b->spare.alloc(b->d.n_pixels * 3));
+        for (uint32_t i = 0; i < b->n_chunks; ++i)
+            b->rgb_dst[i] = i == 0 ? b->spare.as<uint8_t>() : b->dec.sym_ptr + (size_t)(i - 1) * 3 * b->d.padded;
+    } else {
+        for (uint32_t i = 0; i < b->n_chunks; ++i) b->rgb_dst[i] = (uint8_t*)d_rgb_out + (size_t)i * b->d.n_pixels * 3;
+    }
+    return decode_launch(headers, pay, b->dec, b->rgb_dst, st, &b->evs);
 }
 const void* alice_codec_batch_rgb_ptr(const AliceBatch* b, uint32_t chunk) {
-    if (!b || chunk >= b->n_chunks) return nullptr;
-    return b->enc.sym.as<uint8_t>() + (size_t)chunk * 3 * b->d.padded;
+    if (!b || chunk >= b->n_chunks || chunk >= b->rgb_dst.size()) return nullptr;
+    return b->rgb_dst[chunk];
 }
 int alice_codec_batch_decode_finish(AliceBatch* b) {
     clear_error();
@@ -1139,15 +1194,23 @@ int alice_codec_build_histogram(const uint8_t* symbols, uint64_t n, uint32_t his
 }
 
 int alice_codec_freq_table_from_histogram(const uint32_t hist[256], uint16_t cum_freq[256], uint16_t freq[256]) {
+    return alice_codec_freq_table_from_histogram_n(hist, 256, cum_freq, freq);
+}
+// FrequencyTable::from_histogram(&[u32]) for a slice of any length the u8 symbol API can address (src/rans.rs:102-150;
+// the reference's own test_uniform_table_small uses 2, :934-944).  Entries from n_symbols on come back as (0, 0).
+int alice_codec_freq_table_from_histogram_n(const uint32_t* hist, uint32_t n_symbols, uint16_t cum_freq[256], uint16_t freq[256]) {
     clear_error();
     if (!hist || !cum_freq || !freq) return fail(kNullArgument, "null argument");
+    if (n_symbols == 0) return fail(kReferenceDiverges, "empty histogram: the reference divides by zero (uniform(0), src/rans.rs:159)");
+    if (n_symbols > 256) return fail(kInvalidDimensions, "more than 256 symbols: the coders address symbols as u8");
     hipStream_t st;
     TRY(get_stream(&st));
     DevBuf h, t;
     TRY(h.alloc(256 * 4));
     TRY(t.alloc(sizeof(RansTable)));
-    HIP_TRY(hipMemcpyAsync(h.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
-    launch_rans_table(h.as<uint32_t>(), t.as<RansTable>(), 1, st);
+    HIP_TRY(hipMemsetAsync(h.p, 0, 256 * 4, st));
+    HIP_TRY(hipMemcpyAsync(h.p, hist, (size_t)n_symbols * 4, hipMemcpyHostToDevice, st));
+    launch_rans_table(h.as<uint32_t>(), t.as<RansTable>(), 1, st, n_symbols);
     std::vector<RansTable> host(1);
     HIP_TRY(hipMemcpyAsync(host.data(), t.p, sizeof(RansTable), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1206,6 +1269,125 @@ int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t c
     return kOk;
 }
 void alice_codec_test_last_decode_stats(uint32_t out[4]) { if (out) for (int i = 0; i < 4; ++i) out[i] = tl_dec_stats[i]; }
+
+// ---- RansEncoder / RansDecoder as objects that live across calls (src/rans.rs:238-309, 321-389) ----
+
+AliceRansEncoder* alice_codec_rans_encoder_new(void) { clear_error(); return new (std::nothrow) AliceRansEncoder(); }
+void alice_codec_rans_encoder_destroy(AliceRansEncoder* e) { delete e; }
+uint32_t alice_codec_rans_encoder_state(const AliceRansEncoder* e) { return e ? e->state : 0u; }
+
+// encode_symbols(&mut self, symbols, table), :288-294: the symbols in reverse order, from the object's current state.
+// Two calls s1 then s2 leave the same stream as one call on s2 || s1.
+int alice_codec_rans_encoder_encode_symbols(AliceRansEncoder* e, const uint8_t* symbols, uint64_t n, const uint16_t cum_freq[256],
+                                            const uint16_t freq[256]) {
+    clear_error();
+    if (!e || (!symbols && n) || !cum_freq || !freq) return fail(kNullArgument, "null argument");
+    if (!n) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    const uint64_t cap = round_up(2 * n + 4 + 64 + 64, 256);
+    DevBuf ds, dc, df, dt, dout, dres;
+    TRY(ds.alloc(n)); TRY(dc.alloc(512)); TRY(df.alloc(512)); TRY(dt.alloc(sizeof(RansTable))); TRY(dout.alloc(cap)); TRY(dres.alloc(sizeof(RansResult)));
+    HIP_TRY(hipMemcpyAsync(ds.p, symbols, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
+    launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
+    launch_rans_encode(ds.as<uint8_t>(), n, n, dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), 1, st,
+                       0, 0, 0xFFFFFFFFu, 0, 0, e->state, true);
+    RansResult res{};
+    HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (res.flags & kTableDiverges) return fail(kReferenceDiverges, "symbol with table frequency 0 encoded (the reference does not terminate / indexes out of bounds)");
+    if (res.flags & (kRansOverflow | kRansInternal)) return fail(kInternal, "rANS encode failed");
+    std::vector<uint8_t> seg((size_t)res.len);
+    if (res.len) {
+        HIP_TRY(hipMemcpyAsync(seg.data(), dout.as<uint8_t>() + (cap - res.len), res.len, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    e->state = res.final_state;
+    e->bytes += res.len;
+    e->segments.push_back(std::move(seg));
+    return kOk;
+}
+// encode(&mut self, &RansSymbol), :269-285: one symbol given by its (cum_freq, freq) pair
+int alice_codec_rans_encoder_encode(AliceRansEncoder* e, uint16_t cum_freq, uint16_t freq) {
+    if (!e) { clear_error(); return fail(kNullArgument, "null argument"); }
+    uint16_t c[256] = {0}, f[256] = {0};
+    c[0] = cum_freq; f[0] = freq;
+    const uint8_t sym = 0;
+    return alice_codec_rans_encoder_encode_symbols(e, &sym, 1, c, f);
+}
+// finish(self), :298-308: consumes the encoder
+uint8_t* alice_codec_rans_encoder_finish(AliceRansEncoder* e, uint64_t* out_len) {
+    clear_error();
+    if (!e || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
+    const uint64_t total = e->bytes + 4;
+    uint8_t* p = (uint8_t*)malloc(total);
+    if (!p) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    p[0] = (uint8_t)(e->state >> 24); p[1] = (uint8_t)(e->state >> 16); p[2] = (uint8_t)(e->state >> 8); p[3] = (uint8_t)e->state;
+    uint64_t off = 4;
+    for (size_t i = e->segments.size(); i-- > 0;) {
+        if (!e->segments[i].empty()) memcpy(p + off, e->segments[i].data(), e->segments[i].size());
+        off += e->segments[i].size();
+    }
+    *out_len = total;
+    delete e;
+    return p;
+}
+
+AliceRansDecoder* alice_codec_rans_decoder_new(const uint8_t* data, uint64_t len) {   // RansDecoder::new, :330-347
+    clear_error();
+    if (!data && len) { fail(kNullArgument, "null argument"); return nullptr; }
+    AliceRansDecoder* d = new (std::nothrow) AliceRansDecoder();
+    if (!d) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
+    d->input.assign(data, data + len);
+    if (len >= 4) { d->state = ((uint32_t)data[0] << 24) | ((uint32_t)data[1] << 16) | ((uint32_t)data[2] << 8) | data[3]; d->pos = 4; }
+    return d;
+}
+void alice_codec_rans_decoder_destroy(AliceRansDecoder* d) { delete d; }
+int alice_codec_rans_decoder_is_empty(const AliceRansDecoder* d) {   // :385-389
+    return d ? (d->pos >= d->input.size() && d->state < kRansL) : 1;
+}
+uint32_t alice_codec_rans_decoder_state(const AliceRansDecoder* d) { return d ? d->state : 0u; }
+uint64_t alice_codec_rans_decoder_position(const AliceRansDecoder* d) { return d ? d->pos : 0u; }
+// decode_n(&mut self, n, table), :375-381: the next n symbols, continuing from the current state and position
+int alice_codec_rans_decoder_decode_n(AliceRansDecoder* d, uint64_t n, const uint16_t cum_freq[256], const uint16_t freq[256],
+                                      uint8_t* symbols) {
+    clear_error();
+    if (!d || !cum_freq || !freq || (!symbols && n)) return fail(kNullArgument, "null argument");
+    if (!n) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    const uint64_t len = d->input.size();
+    DevBuf din, dc, df, dt, dout, ddesc, dres;
+    TRY(din.alloc(len + 16)); TRY(dc.alloc(512)); TRY(df.alloc(512)); TRY(dt.alloc(sizeof(RansTable)));
+    TRY(dout.alloc(n)); TRY(ddesc.alloc(sizeof(RansDecodeDesc))); TRY(dres.alloc(sizeof(RansResult)));
+    if (len) HIP_TRY(hipMemcpyAsync(din.p, d->input.data(), len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
+    RansDecodeDesc desc{din.as<uint8_t>(), len, dout.as<uint8_t>(), n, dt.as<RansTable>(), 1u, d->state, d->pos};
+    HIP_TRY(hipMemcpyAsync(ddesc.p, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
+    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 1, st);
+    RansResult res{};
+    HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(symbols, dout.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    note_decode_stats(res);
+    if (res.flags & kRansInternal) return fail(kInternal, "rANS decode kernel invariant violated");
+    d->state = res.final_state;
+    d->pos = res.len;
+    d->started = true;
+    return kOk;
+}
+
+// quantize_subband / dequantize_subband (src/quant.rs:518-545): a sub-band's coefficients through a Quantizer
+int alice_codec_quantize_subband(int32_t step, int32_t dead_zone, const int32_t* coeffs, uint64_t n, int32_t* out, uint64_t n_out) {
+    return alice_codec_quantize_buffer(step, dead_zone, coeffs, n, out, n_out);
+}
+int alice_codec_dequantize_subband(int32_t step, const int32_t* coeffs, uint64_t n, int32_t* out, uint64_t n_out) {
+    return alice_codec_dequantize_buffer(step, coeffs, n, out, n_out);
+}
 
 // ssim / ms_ssim (src/ssim.rs:63-176).  Returns the value, or -1.0 with the thread's error set (the Result::Err cases).
 static int ssim_device(const uint8_t* d_a, const uint8_t* d_b, uint64_t w, uint64_t h, double* d_blocks, double* d_acc,
@@ -1469,9 +1651,115 @@ int alice_codec_ycocg_r_to_rgb(const int16_t* y, const int16_t* co, const int16_
 // ---- many chunks from host memory in one call: the chunk driver's fast path (the chains of all chunks run side
 // by side; a single chunk is bound by its three serial chains) ----
 
-int alice_codec_encode_many(const FrameEncoder* encoder, const uint8_t* rgb, uint64_t rgb_len, uint32_t width, uint32_t height,
-                            uint32_t frames, uint32_t n_chunks, EncodedChunk** out_chunks) {
-    clear_error();
+// How many chunks of this shape the calling thread's device can hold at once (inputs or outputs, symbols, .alc
+// buffers with the worst observed payload of 1 byte per pixel sample, tables), leaving a fifth of the free memory alone.
+static uint32_t chunks_that_fit(const ChunkDims& d, uint32_t want) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return want; }
+    const long double per_chunk = (long double)d.n_pixels * 3 + (long double)d.padded * 3 * 2 + 3.0L * sizeof(RansTable) * 2 + 65536;
+    const long double fixed = (long double)std::max(forward_scratch_bytes(d), inverse_scratch_bytes(d, false)) + (64u << 20);
+    const long double room = (long double)free_b * 0.8L - fixed;
+    if (room < per_chunk) return 1;
+    const long double n = room / per_chunk;
+    return n >= (long double)want ? want : (uint32_t)n;
+}
+
+// Encodes the chunks at rgb[i] (host pointers, n_pixels * 3 bytes each) on the calling thread's device, as many at a
+// time as its memory holds; out[i] receives the chunk objects.  On error nothing is left in out.
+static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<const uint8_t*>& rgb, const ChunkDims& d,
+                                   const std::vector<EncodedChunk**>& out) {
+    const uint32_t n = (uint32_t)rgb.size();
+    for (uint32_t i = 0; i < n; ++i) *out[i] = nullptr;
+    if (!n) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    auto undo = [&](int rc) { for (uint32_t k = 0; k < n; ++k) { delete *out[k]; *out[k] = nullptr; } return rc; };
+    const uint64_t chunk_bytes = d.n_pixels * 3;
+    const uint32_t per_pass = chunks_that_fit(d, n);
+    for (uint32_t first = 0; first < n; first += per_pass) {
+        const uint32_t B = std::min(per_pass, n - first);
+        DevBuf d_rgb;
+        EncodeWork w;
+        std::vector<RansResult> res;
+        int rc = d_rgb.alloc(chunk_bytes * B);
+        if (rc == kOk) rc = encode_work_alloc(w, d, (int)B);
+        if (rc != kOk) return undo(rc);
+        for (uint32_t i = 0; i < B; ++i)
+            if (hipMemcpyAsync(d_rgb.as<uint8_t>() + (size_t)i * chunk_bytes, rgb[first + i], chunk_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+                return undo(fail(kDeviceError, "host to device copy failed"));
+        for (int attempt = 0;; ++attempt) {
+            rc = encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, attempt ? worst_cap(d) : 0);
+            if (rc != kOk) return undo(rc);
+            rc = encode_collect(w, st, res);
+            if (rc == kOk) break;
+            if (rc != -1 || attempt > 0) return undo(rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc);
+        }
+        std::vector<uint8_t> alc;
+        for (uint32_t i = 0; i < B; ++i) {
+            const uint64_t payload = res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
+            alc.resize((size_t)kAlcHeaderBytes + payload);
+            if (hipMemcpyAsync(alc.data(), w.alc.as<uint8_t>() + (size_t)i * w.alc_stride, alc.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return undo(fail(kDeviceError, "device to host copy failed"));
+            EncodedChunk* c = new (std::nothrow) EncodedChunk();
+            uint64_t tot = 0;
+            if (!c || parse_alc_header(alc.data(), alc.size(), *c, &tot) != kOk || tot != payload) {
+                delete c;
+                return undo(fail(kInternal, "device header/payload length mismatch"));
+            }
+            c->data.assign(alc.begin() + kAlcHeaderBytes, alc.end());
+            *out[first + i] = c;
+        }
+    }
+    return kOk;
+}
+
+// Decodes chunks (all of one shape, validated by the caller) on the calling thread's device into rgb_out[i].
+static int decode_chunks_on_device(const std::vector<const EncodedChunk*>& chunks, const ChunkDims& d, const std::vector<uint8_t*>& rgb_out) {
+    const uint32_t n = (uint32_t)chunks.size();
+    if (!n || d.n_pixels == 0) return kOk;
+    hipStream_t st;
+    TRY(get_stream(&st));
+    const uint64_t chunk_bytes = d.n_pixels * 3;
+    const uint32_t per_pass = chunks_that_fit(d, n);
+    for (uint32_t first = 0; first < n; first += per_pass) {
+        const uint32_t B = std::min(per_pass, n - first);
+        std::vector<EncodedChunk> hdrs(B);
+        uint64_t total_payload = 0;
+        for (uint32_t i = 0; i < B; ++i) {
+            const EncodedChunk& c = *chunks[first + i];
+            hdrs[i].width = c.width; hdrs[i].height = c.height; hdrs[i].frames = c.frames; hdrs[i].wavelet = c.wavelet;
+            for (int k = 0; k < 3; ++k) hdrs[i].ch[k] = c.ch[k];
+            total_payload += round_up(c.data.size() + 16, 256);
+        }
+        DevBuf d_payload, d_rgb;
+        TRY(d_payload.alloc(total_payload + 256));
+        TRY(d_rgb.alloc(chunk_bytes * B));
+        std::vector<const uint8_t*> pay(B);
+        std::vector<uint8_t*> dst(B);
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < B; ++i) {
+            const EncodedChunk& c = *chunks[first + i];
+            pay[i] = d_payload.as<uint8_t>() + off;
+            dst[i] = d_rgb.as<uint8_t>() + (size_t)i * chunk_bytes;
+            if (!c.data.empty())
+                HIP_TRY(hipMemcpyAsync(d_payload.as<uint8_t>() + off, c.data.data(), c.data.size(), hipMemcpyHostToDevice, st));
+            off += round_up(c.data.size() + 16, 256);
+        }
+        DecodeWork w;
+        TRY(decode_work_alloc(w, d, (int)B));
+        TRY(decode_launch(hdrs, pay, w, dst, st, nullptr));
+        TRY(decode_collect(w, st));
+        for (uint32_t i = 0; i < B; ++i)
+            HIP_TRY(hipMemcpyAsync(rgb_out[first + i], dst[i], chunk_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return kOk;
+}
+
+// validation shared by the many-chunk encode entry points (FrameEncoder::encode's, src/pipeline.rs:388-427, per chunk)
+static int validate_encode_many(const FrameEncoder* encoder, const uint8_t* rgb, uint64_t rgb_len, uint32_t width, uint32_t height,
+                                uint32_t frames, uint32_t n_chunks, EncodedChunk** out_chunks, ChunkDims* d) {
     if (!encoder || !out_chunks || (!rgb && rgb_len)) return fail(kNullArgument, "null argument");
     for (uint32_t i = 0; i < n_chunks; ++i) out_chunks[i] = nullptr;
     if (n_chunks == 0) return kOk;
@@ -1481,43 +1769,11 @@ int alice_codec_encode_many(const FrameEncoder* encoder, const uint8_t* rgb, uin
     if (n_pixels > UINT64_MAX / 3 / n_chunks) return fail(kDimensionOverflow, "dimensions overflow usize");
     if (rgb_len != n_pixels * 3 * n_chunks)
         return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(n_pixels * 3 * n_chunks) + ", got " + std::to_string(rgb_len));
-    const ChunkDims d = make_dims(width, height, frames);
-    if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count does not fit the header's u32 num_symbols");
-    hipStream_t st;
-    TRY(get_stream(&st));
-    DevBuf d_rgb;
-    TRY(d_rgb.alloc(rgb_len));
-    HIP_TRY(hipMemcpyAsync(d_rgb.p, rgb, rgb_len, hipMemcpyHostToDevice, st));
-    EncodeWork w;
-    std::vector<RansResult> res;
-    TRY(encode_work_alloc(w, d, (int)n_chunks));
-    for (int attempt = 0;; ++attempt) {
-        TRY(encode_launch(d_rgb.as<uint8_t>(), w, encoder->quality, encoder->wavelet, st, nullptr, attempt ? worst_cap(d) : 0));
-        const int rc = encode_collect(w, st, res);
-        if (rc == kOk) break;
-        if (rc != -1 || attempt > 0) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
-    }
-    std::vector<uint8_t> alc;
-    for (uint32_t i = 0; i < n_chunks; ++i) {
-        const uint64_t payload = res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
-        alc.resize((size_t)kAlcHeaderBytes + payload);
-        HIP_TRY(hipMemcpyAsync(alc.data(), w.alc.as<uint8_t>() + (size_t)i * w.alc_stride, alc.size(), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        EncodedChunk* c = new (std::nothrow) EncodedChunk();
-        uint64_t tot = 0;
-        if (!c || parse_alc_header(alc.data(), alc.size(), *c, &tot) != kOk || tot != payload) {
-            delete c;
-            for (uint32_t k = 0; k < i; ++k) { delete out_chunks[k]; out_chunks[k] = nullptr; }
-            return fail(kInternal, "device header/payload length mismatch");
-        }
-        c->data.assign(alc.begin() + kAlcHeaderBytes, alc.end());
-        out_chunks[i] = c;
-    }
+    *d = make_dims(width, height, frames);
+    if (d->padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count does not fit the header's u32 num_symbols");
     return kOk;
 }
-
-int alice_codec_decode_many(const EncodedChunk* const* chunks, uint32_t n_chunks, uint8_t* rgb_out, uint64_t rgb_out_len) {
-    clear_error();
+static int validate_decode_many(const EncodedChunk* const* chunks, uint32_t n_chunks, uint8_t* rgb_out, uint64_t rgb_out_len, ChunkDims* d) {
     if (!chunks || (!rgb_out && rgb_out_len)) return fail(kNullArgument, "null argument");
     if (n_chunks == 0) return kOk;
     for (uint32_t i = 0; i < n_chunks; ++i) {
@@ -1525,38 +1781,112 @@ int alice_codec_decode_many(const EncodedChunk* const* chunks, uint32_t n_chunks
         if (chunks[i]->width != chunks[0]->width || chunks[i]->height != chunks[0]->height || chunks[i]->frames != chunks[0]->frames)
             return fail(kInvalidDimensions, "chunks of one call must have the same shape");
     }
-    ChunkDims d;
-    std::vector<EncodedChunk> hdrs(n_chunks);
-    uint64_t total_payload = 0;
-    for (uint32_t i = 0; i < n_chunks; ++i) {
-        TRY(validate_for_decode(*chunks[i], &d, chunks[i]->data.size()));
-        hdrs[i].width = chunks[i]->width; hdrs[i].height = chunks[i]->height; hdrs[i].frames = chunks[i]->frames; hdrs[i].wavelet = chunks[i]->wavelet;
-        for (int k = 0; k < 3; ++k) hdrs[i].ch[k] = chunks[i]->ch[k];
-        total_payload += round_up(chunks[i]->data.size() + 16, 256);
-    }
-    if (d.n_pixels == 0) return rgb_out_len == 0 ? kOk : fail(kInvalidBufferSize, "output buffer size mismatch");
-    if (rgb_out_len != d.n_pixels * 3 * n_chunks)
-        return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(d.n_pixels * 3 * n_chunks) + ", got " + std::to_string(rgb_out_len));
-    hipStream_t st;
-    TRY(get_stream(&st));
-    DevBuf d_payload, d_rgb;
-    TRY(d_payload.alloc(total_payload + 256));
-    TRY(d_rgb.alloc(rgb_out_len));
-    std::vector<const uint8_t*> pay(n_chunks);
-    uint64_t off = 0;
-    for (uint32_t i = 0; i < n_chunks; ++i) {
-        pay[i] = d_payload.as<uint8_t>() + off;
-        if (!chunks[i]->data.empty())
-            HIP_TRY(hipMemcpyAsync(d_payload.as<uint8_t>() + off, chunks[i]->data.data(), chunks[i]->data.size(), hipMemcpyHostToDevice, st));
-        off += round_up(chunks[i]->data.size() + 16, 256);
-    }
-    DecodeWork w;
-    TRY(decode_work_alloc(w, d, (int)n_chunks));
-    TRY(decode_launch(hdrs, pay, w, d_rgb.as<uint8_t>(), st, nullptr));
-    TRY(decode_collect(w, st));
-    HIP_TRY(hipMemcpyAsync(rgb_out, d_rgb.p, rgb_out_len, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < n_chunks; ++i) TRY(validate_for_decode(*chunks[i], d, chunks[i]->data.size()));
+    if (d->n_pixels == 0) return rgb_out_len == 0 ? kOk : fail(kInvalidBufferSize, "output buffer size mismatch");
+    if (rgb_out_len != d->n_pixels * 3 * n_chunks)
+        return fail(kInvalidBufferSize, "buffer size mismatch: expected " + std::to_string(d->n_pixels * 3 * n_chunks) + ", got " + std::to_string(rgb_out_len));
     return kOk;
+}
+
+int alice_codec_encode_many(const FrameEncoder* encoder, const uint8_t* rgb, uint64_t rgb_len, uint32_t width, uint32_t height,
+                            uint32_t frames, uint32_t n_chunks, EncodedChunk** out_chunks) {
+    clear_error();
+    ChunkDims d{};
+    TRY(validate_encode_many(encoder, rgb, rgb_len, width, height, frames, n_chunks, out_chunks, &d));
+    if (n_chunks == 0) return kOk;
+    std::vector<const uint8_t*> src(n_chunks);
+    std::vector<EncodedChunk**> dst(n_chunks);
+    for (uint32_t i = 0; i < n_chunks; ++i) { src[i] = rgb + (size_t)i * d.n_pixels * 3; dst[i] = &out_chunks[i]; }
+    return encode_chunks_on_device(*encoder, src, d, dst);
+}
+
+int alice_codec_decode_many(const EncodedChunk* const* chunks, uint32_t n_chunks, uint8_t* rgb_out, uint64_t rgb_out_len) {
+    clear_error();
+    ChunkDims d{};
+    TRY(validate_decode_many(chunks, n_chunks, rgb_out, rgb_out_len, &d));
+    if (n_chunks == 0 || d.n_pixels == 0) return kOk;
+    std::vector<const EncodedChunk*> src(chunks, chunks + n_chunks);
+    std::vector<uint8_t*> dst(n_chunks);
+    for (uint32_t i = 0; i < n_chunks; ++i) dst[i] = rgb_out + (size_t)i * d.n_pixels * 3;
+    return decode_chunks_on_device(src, d, dst);
+}
+
+// ---- the same over several GPUs of the node: chunk k goes to devices[k mod n_devices] (64-frame chunks are independent
+// bitstreams, src/pipeline.rs:461-497: no cross-chunk state), one host thread and one stream per listed device, every
+// device moves its own chunks over its own PCIe link, results land in the caller's arrays in chunk order ----
+
+int alice_codec_many_devices_plan(uint32_t n_chunks, const int* devices, uint32_t n_devices, int* device_of_chunk) {
+    clear_error();
+    if ((!devices && n_devices) || (!device_of_chunk && n_chunks)) return fail(kNullArgument, "null argument");
+    if (n_devices == 0) return fail(kDeviceError, "empty device list");
+    for (uint32_t i = 0; i < n_devices; ++i)
+        if (devices[i] < 0) return fail(kDeviceError, "negative device index");
+    for (uint32_t k = 0; k < n_chunks; ++k) device_of_chunk[k] = devices[k % n_devices];
+    return kOk;
+}
+
+}  // extern "C"
+namespace {
+struct WorkerResult { int code = kOk; std::string msg; };
+// runs fn(slot) on one thread per slot of the device list, each bound to its device; returns the first failure
+template <typename Fn>
+int run_on_devices(const int* devices, uint32_t n_devices, Fn fn) {
+    const int count = alice_codec_device_count();
+    for (uint32_t i = 0; i < n_devices; ++i)
+        if (devices[i] >= count) return fail(kDeviceError, "device index " + std::to_string(devices[i]) + " out of range (" + std::to_string(count) + " visible)");
+    std::vector<WorkerResult> res(n_devices);
+    std::vector<std::thread> th;
+    th.reserve(n_devices);
+    for (uint32_t s = 0; s < n_devices; ++s)
+        th.emplace_back([&, s] {
+            clear_error();
+            tl_device = devices[s];
+            int rc = ensure_device();
+            if (rc == kOk) rc = fn(s);
+            res[s].code = rc;
+            if (rc != kOk) res[s].msg = tl_msg;
+        });
+    for (auto& t : th) t.join();
+    for (uint32_t s = 0; s < n_devices; ++s)
+        if (res[s].code != kOk) return fail(res[s].code, "device " + std::to_string(devices[s]) + ": " + res[s].msg);
+    return kOk;
+}
+}  // namespace
+extern "C" {
+
+int alice_codec_encode_many_devices(const FrameEncoder* encoder, const uint8_t* rgb, uint64_t rgb_len, uint32_t width, uint32_t height,
+                                    uint32_t frames, uint32_t n_chunks, const int* devices, uint32_t n_devices, EncodedChunk** out_chunks) {
+    clear_error();
+    ChunkDims d{};
+    TRY(validate_encode_many(encoder, rgb, rgb_len, width, height, frames, n_chunks, out_chunks, &d));
+    std::vector<int> plan(n_chunks);
+    TRY(alice_codec_many_devices_plan(n_chunks, devices, n_devices, plan.data()));
+    if (n_chunks == 0) return kOk;
+    const int rc = run_on_devices(devices, n_devices, [&](uint32_t slot) {
+        std::vector<const uint8_t*> src;
+        std::vector<EncodedChunk**> dst;
+        for (uint32_t k = slot; k < n_chunks; k += n_devices) { src.push_back(rgb + (size_t)k * d.n_pixels * 3); dst.push_back(&out_chunks[k]); }
+        return encode_chunks_on_device(*encoder, src, d, dst);
+    });
+    if (rc != kOk)
+        for (uint32_t k = 0; k < n_chunks; ++k) { delete out_chunks[k]; out_chunks[k] = nullptr; }
+    return rc;
+}
+
+int alice_codec_decode_many_devices(const EncodedChunk* const* chunks, uint32_t n_chunks, const int* devices, uint32_t n_devices,
+                                    uint8_t* rgb_out, uint64_t rgb_out_len) {
+    clear_error();
+    ChunkDims d{};
+    TRY(validate_decode_many(chunks, n_chunks, rgb_out, rgb_out_len, &d));
+    std::vector<int> plan(n_chunks);
+    TRY(alice_codec_many_devices_plan(n_chunks, devices, n_devices, plan.data()));
+    if (n_chunks == 0 || d.n_pixels == 0) return kOk;
+    return run_on_devices(devices, n_devices, [&](uint32_t slot) {
+        std::vector<const EncodedChunk*> src;
+        std::vector<uint8_t*> dst;
+        for (uint32_t k = slot; k < n_chunks; k += n_devices) { src.push_back(chunks[k]); dst.push_back(rgb_out + (size_t)k * d.n_pixels * 3); }
+        return decode_chunks_on_device(src, d, dst);
+    });
 }
 
 // ---- PART 3: device-resident stage calls (building blocks of the row-slab sharded path) ----
@@ -1578,12 +1908,13 @@ int alice_codec_dev_forward_symbols(const void* d_rgb, uint32_t width, uint32_t 
     tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     EncodeWork w;
     w.d = d; w.n_chunks = 1;
-    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
+    const bool tiles = transform_tiles_eligible(d);
+    if (tiles) TRY(w.scratch.alloc(forward_scratch_bytes(d)));
     TRY(w.hist.alloc(3 * 256 * sizeof(uint32_t)));
     uint32_t* hist = d_hist ? (uint32_t*)d_hist : w.hist.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(hist, 0, 3 * 256 * sizeof(uint32_t), st));
     const int32_t step = quality_to_step(quality);
-    if (!launch_forward_transform((const uint8_t*)d_rgb, d, wavelet_type, step, w.mid.as<int32_t>(), (uint8_t*)d_symbols, hist, st))
+    if (!tiles || !launch_forward_transform((const uint8_t*)d_rgb, d, wavelet_type, step, w.scratch.p, (uint8_t*)d_symbols, hist, st))
         TRY(forward_generic((const uint8_t*)d_rgb, d, wavelet_type, step, w, (uint8_t*)d_symbols, hist, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
@@ -1605,10 +1936,10 @@ int alice_codec_dev_inverse_symbols(const void* d_symbols, uint32_t width, uint3
     tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
     DecodeWork w;
     w.d = d; w.n_chunks = 1;
-    TRY(w.mid.alloc(3 * d.padded * sizeof(int32_t)));
-    w.mid_ptr = w.mid.as<int32_t>();
     const InverseBounds ib = inverse_bounds(wavelet_type, step);
-    if (!launch_inverse_transform((const uint8_t*)d_symbols, d, wavelet_type, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.mid_ptr, (uint8_t*)d_rgb, st))
+    const bool tiles = transform_tiles_eligible(d);
+    if (tiles) TRY(w.scratch_own.alloc(inverse_scratch_bytes(d, ib.fast && ib.mid16)));
+    if (!tiles || !launch_inverse_transform((const uint8_t*)d_symbols, d, wavelet_type, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.scratch_own.p, (uint8_t*)d_rgb, st))
         TRY(inverse_generic((const uint8_t*)d_symbols, d, wavelet_type, step, w, (uint8_t*)d_rgb, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
@@ -1701,6 +2032,81 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
     HIP_TRY(hipStreamSynchronize(st));
     note_decode_stats(res);
     if (res.flags & kRansInternal) return fail(kInternal, "rANS decode table invariant violated");
+    return kOk;
+}
+
+
+// ---- test and measurement hooks (include/alice_codec_test.h) ----
+
+void alice_codec_test_set_tuning(long band_kb, long t_blocks, long no_fuse) { set_transform_tuning(band_kb, t_blocks, no_fuse); }
+
+int alice_codec_test_chain_occupancy(uint32_t out[6]) {
+    clear_error();
+    if (!out) return fail(kNullArgument, "null argument");
+    TRY(ensure_device());
+    if (!chain_kernel_occupancy(out)) return fail(kDeviceError, "hipFuncGetAttributes / occupancy query failed");
+    return kOk;
+}
+
+int alice_codec_test_transform_ms(const void* d_rgb, void* d_sym, void* d_rgb_out, uint32_t n_buffers, uint32_t width,
+                                  uint32_t height, uint32_t frames, uint8_t wavelet_type, uint8_t quality, uint32_t n_chunks,
+                                  uint32_t reps, int probe, float out_ms[2], void* hip_stream) {
+    clear_error();
+    if (!d_rgb || !d_sym || !d_rgb_out || !out_ms || !n_buffers || !n_chunks || !reps) return fail(kNullArgument, "null argument");
+    if (wavelet_type > 2) return fail(kInvalidBitstream, "unknown wavelet type");
+    uint64_t n_pixels = 0;
+    TRY(checked_pixel_count(width, height, frames, &n_pixels));
+    if (n_pixels == 0) return fail(kInvalidDimensions, "invalid dimensions");
+    const ChunkDims d = make_dims(width, height, frames);
+    if (!transform_tiles_eligible(d)) return fail(kInvalidDimensions, "shape runs the generic path: nothing to time");
+    TRY(ensure_device());
+    hipStream_t st = (hipStream_t)hip_stream;
+    tl_scope_stream = st;
+    const int32_t step = quality_to_step(quality);
+    const int32_t steps[3] = {step, step, step};
+    const InverseBounds ib = inverse_bounds(wavelet_type, steps);
+    DevBuf scratch, hist;
+    TRY(scratch.alloc(std::max(forward_scratch_bytes(d), inverse_scratch_bytes(d, ib.fast && ib.mid16))));
+    TRY(hist.alloc(3 * 256 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(hist.p, 0, 3 * 256 * sizeof(uint32_t), st));
+    StageEvents ev;
+    TRY(ev.init());
+    set_transform_probe(probe);
+    auto fwd = [&]() {
+        ForwardPipe pipe;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t k = c % n_buffers;
+            pipe.enqueue((const uint8_t*)d_rgb + (size_t)k * d.n_pixels * 3, d, wavelet_type, step, scratch.p,
+                         (uint8_t*)d_sym + (size_t)k * 3 * d.padded, hist.as<uint32_t>(), st);
+        }
+        pipe.flush(st);
+    };
+    auto inv = [&]() {
+        InversePipe pipe;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t k = c % n_buffers;
+            pipe.enqueue((const uint8_t*)d_sym + (size_t)k * 3 * d.padded, d, wavelet_type, steps, !ib.fast, ib.fast && ib.mid16,
+                         ib.fast && ib.lds16, scratch.p, (uint8_t*)d_rgb_out + (size_t)k * d.n_pixels * 3, st);
+        }
+        pipe.flush(st);
+    };
+    fwd();   // warm-up; also leaves real symbols for the inverse
+    hipError_t e = hipEventRecord(ev.ev[0], st);
+    for (uint32_t r = 0; r < reps && e == hipSuccess; ++r) fwd();
+    if (e == hipSuccess) e = hipEventRecord(ev.ev[1], st);
+    inv();
+    if (e == hipSuccess) e = hipEventRecord(ev.ev[2], st);
+    for (uint32_t r = 0; r < reps && e == hipSuccess; ++r) inv();
+    if (e == hipSuccess) e = hipEventRecord(ev.ev[3], st);
+    set_transform_probe(0);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(kDeviceError, hipGetErrorString(e));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, ev.ev[0], ev.ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, ev.ev[2], ev.ev[3]));
+    out_ms[0] = a / (float)(reps * n_chunks);
+    out_ms[1] = b / (float)(reps * n_chunks);
     return kOk;
 }
 

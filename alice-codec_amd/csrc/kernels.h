@@ -40,10 +40,16 @@ struct RansDecodeDesc {
     uint8_t* out;             // n symbols
     unsigned long long n;
     const RansTable* table;   // built by rans_table_kernel from the stored channel histogram
+    // a RansDecoder object that has decoded before continues from where it stopped (src/rans.rs:351-381): state and
+    // position of the next stream byte instead of the four head bytes
+    uint32_t resume, x0;
+    unsigned long long pos0;
 };
 
 // ---- rans.hip ----
-void launch_rans_table(const uint32_t* d_hist, RansTable* d_tables, int n_chains, hipStream_t st);
+// n_symbols <= 256: length of the histogram slice (FrequencyTable::from_histogram(&[u32]), src/rans.rs:102-104); bins from
+// n_symbols on are ignored and the symbols do not exist in the table (freq 0)
+void launch_rans_table(const uint32_t* d_hist, RansTable* d_tables, int n_chains, hipStream_t st, uint32_t n_symbols = 256);
 void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq, RansTable* d_table,
                                    hipStream_t st);
 // chain c reads sym + c*sym_stride (n symbols) and writes its stream back-to-front into a cap-sized region;
@@ -55,7 +61,9 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
                         uint64_t group_stride = 0, uint64_t group_head = 0, unsigned n_split = 0xFFFFFFFFu,
-                        uint64_t cap_co = 0, uint64_t cap_cg = 0);
+                        uint64_t cap_co = 0, uint64_t cap_cg = 0, uint32_t x_init = kRansL, bool keep_open = false);
+// x_init / keep_open: a RansEncoder object between calls (src/rans.rs:269-294): the chain starts from the object's state
+// and leaves the four state bytes of finish() unwritten (results[c].final_state carries the state on)
 // out_j[k] = in[4k + j] for the four sub-sequences of an interleaved stream (out_j = out + j*stride)
 void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t stride, hipStream_t st);
 // InterleavedRansDecoder::decode_n order (src/rans.rs:501-519): symbol k of stream j lands at
@@ -64,19 +72,84 @@ void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t str
 void launch_merge4(const uint8_t* d_in, uint64_t stride, const uint64_t have[4], const uint64_t count[4], uint8_t* d_out,
                    uint64_t n_out, hipStream_t st);
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
+// what the runtime reports for the one-chain-per-SIMD instances: out[0..2] = encoder registers per lane (VGPR + AGPR),
+// static LDS bytes, workgroups per CU it would co-schedule; out[3..5] = decoder.  False when a query failed.
+bool chain_kernel_occupancy(uint32_t out[6]);
 
 // ---- transform.hip (pipeline-specialised: RGB <-> u8 symbols) ----
-// mid: scratch of 3 * padded int32 for one chunk (used as i16 by the forward path).  hist: uint32 [3][256],
-// zeroed by the caller.  Returns false when the shape needs the generic path: a padded width or height
-// below 6 (the tile kernels read their halo through one reflection), a frame of more than 2^30 samples
-// (32-bit offsets inside a frame), or more tiles than a 1-D grid holds.
+// A chunk is processed in BANDS of whole tile rows so that a band's intermediate (i16 after the spatial pass, i16 / i32
+// after the inverse temporal pass) stays in the Infinity Cache between the two passes, and every launch runs the
+// temporal role of one band beside the tile role of its neighbour (transform.hip, "Band-ordered, role-fused launches").
+struct BandPlan {
+    int tile_h, tiles_y;   // tile height of the tile role, tile rows of the frame
+    int tpb, n_bands;      // tile rows per band, bands (1 = the frame is not cut)
+    int slots;             // band slots the scratch holds (2 when cut: producer and consumer of neighbouring bands overlap)
+    size_t slot_bytes;
+};
+// false: the shape needs the generic path -- a padded width or height below 6 (the tile kernels read their halo
+// through one reflection), a frame of more than 2^30 samples (32-bit offsets inside a frame), or more tiles than a
+// 1-D grid holds.
+bool transform_tiles_eligible(const ChunkDims& d);
+// scratch (band slots) the forward / inverse launches of a chunk of this shape need; the caller owns the buffer
+size_t forward_scratch_bytes(const ChunkDims& d);
+size_t inverse_scratch_bytes(const ChunkDims& d, bool mid16);
+
+struct FwdXy; struct FwdTm; struct InvXy; struct InvTm;   // role arguments (transform.hip)
+
+// Enqueues the launches of chunk after chunk on one stream.  The temporal role of a chunk's last band stays pending and
+// rides in the first launch of the next chunk (flush() runs it alone), so a batch of chunks never drains the device
+// between chunks.  hist: uint32 [3][256], zeroed by the caller.  enqueue returns false (nothing launched) when the shape
+// needs the generic path.  All chunks that share launches must use the same scratch buffer.
+class ForwardPipe {
+public:
+    ForwardPipe();
+    ~ForwardPipe();
+    ForwardPipe(const ForwardPipe&) = delete;
+    ForwardPipe& operator=(const ForwardPipe&) = delete;
+    bool enqueue(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step, void* d_scratch, uint8_t* d_sym,
+                 uint32_t* d_hist, hipStream_t st);
+    void flush(hipStream_t st);
+private:
+    void launch(const FwdXy* xa, const FwdTm* ta, hipStream_t st);
+    FwdTm* pending_;
+    bool has_pending_ = false;
+    int ns_ = 0, slot_ = 0;
+    bool step1_ = false;
+    void* scratch_ = nullptr;
+    size_t slot_bytes_ = 0;
+};
+// steps per channel come from the chunk header.  exact = 64-bit lifting products.  mid16 = the intermediate after the
+// temporal pass provably fits i16 (halves its traffic); lds16 = so does everything after the column pass (packed tile).
+// Here the pending role is the tile role of the chunk's last band (it writes d_rgb: the chunk's pixels are complete
+// only after the next enqueue or flush).
+class InversePipe {
+public:
+    InversePipe();
+    ~InversePipe();
+    InversePipe(const InversePipe&) = delete;
+    InversePipe& operator=(const InversePipe&) = delete;
+    bool enqueue(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3], bool exact, bool mid16,
+                 bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st);
+    void flush(hipStream_t st);
+private:
+    void launch(const InvXy* xa, const InvTm* ta, hipStream_t st);
+    InvXy* pending_;
+    bool has_pending_ = false;
+    int ns_ = 0, slot_ = 0, variant_ = -1;
+    void* scratch_ = nullptr;
+    size_t slot_bytes_ = 0;
+};
+// measurement only (alice_codec_test_transform_ms): the calling thread's next launches of the CDF 9/7 instances run their
+// VALU-floor twins (same instruction streams, global loads and stores replaced by register moves)
+void set_transform_probe(int mode);   // 0 off, 1 loads and stores replaced, 2 loads only, 3 stores only
+// tuning of the band plan (negative = keep): slot target in KiB (0 = never cut), cap on the temporal role's workgroups per
+// launch (0 = no cap), 1 = every role in a launch of its own.  Process-wide; meant for tests and probes.
+void set_transform_tuning(long band_kb, long t_blocks, long no_fuse);
+// one chunk, both roles flushed: enqueue + flush
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
-                              int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st);
-// steps/dead zones per channel come from the chunk header.  exact = 64-bit lifting products.
-// mid16 = the intermediate after the temporal pass provably fits i16 (halves its traffic); lds16 = so does
-// everything after the column pass (halves the tile kernel's LDS footprint).
+                              void* d_scratch, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st);
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
-                              bool exact, bool mid16, bool lds16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st);
+                              bool exact, bool mid16, bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st);
 
 // ---- transform.hip, stage level: Wavelet2D / Wavelet3D of caller-shaped i32 data on the tile kernels' exact instances ----
 // eligible: even width and height >= 6, even depth (or depth 1); otherwise the caller uses launch_wavelet_axis.

@@ -34,11 +34,14 @@ namespace alice {
 // Frequency table (device function shared by the table kernel and the decoder)
 // ----------------------------------------------------------------------------------
 
-// Computes the reference table for a 256-bin histogram.  Must be called by the first
-// 256 threads of a block (all of them), s = threadIdx.x; scratch: 256+ u32 in LDS.
-// Returns freq/cum as the reference stores them (u16 truncated).
-__device__ inline void freq_table_256(uint32_t count, uint32_t* scratch, uint32_t& freq16, uint32_t& cum16) {
+// Computes the reference table for a histogram of n_sym <= 256 bins (FrequencyTable::from_histogram takes any slice,
+// src/rans.rs:102-104; the pipeline always passes 256).  Must be called by the first 256 threads of a block (all of
+// them), s = threadIdx.x; scratch: 256+ u32 in LDS; count = 0 for s >= n_sym.
+// Returns freq/cum as the reference stores them (u16 truncated); symbols s >= n_sym do not exist: freq = cum = 0.
+__device__ inline void freq_table_256(uint32_t count, uint32_t n_sym, uint32_t* scratch, uint32_t& freq16, uint32_t& cum16) {
     const int s = threadIdx.x;
+    const bool exists = (uint32_t)s < n_sym;
+    const uint32_t last = n_sym - 1u;
     __shared__ unsigned long long total_sh;
     if (s == 0) total_sh = 0ull;
     __syncthreads();
@@ -46,8 +49,10 @@ __device__ inline void freq_table_256(uint32_t count, uint32_t* scratch, uint32_
     __syncthreads();
     const unsigned long long total = total_sh;
     uint32_t freq;
-    if (total == 0ull) {
-        freq = kProbScale / 256u;  // uniform(256): src/rans.rs:159-166
+    if (!exists) {
+        freq = 0u;
+    } else if (total == 0ull) {
+        freq = (kProbScale / n_sym) & 0xFFFFu;  // uniform(n): src/rans.rs:159-166
     } else {
         if (count == 0u) freq = 1u;  // src/rans.rs:117-118
         else {
@@ -70,14 +75,14 @@ __device__ inline void freq_table_256(uint32_t count, uint32_t* scratch, uint32_
     uint32_t cum = incl - freq;
     if (total == 0ull) {
         // uniform: last.freq = 4096 - last.cum (src/rans.rs:169-172)
-        if (s == 255) freq = (kProbScale - cum) & 0xFFFFu;
-    } else if (s == 255 && nt != kProbScale) {
+        if ((uint32_t)s == last) freq = (kProbScale - cum) & 0xFFFFu;
+    } else if ((uint32_t)s == last && nt != kProbScale) {
         // src/rans.rs:128-132: wrapping cast to u16
         int32_t diff = (int32_t)kProbScale - (int32_t)nt;
         freq = (uint32_t)((int32_t)freq + diff) & 0xFFFFu;
     }
-    freq16 = freq & 0xFFFFu;
-    cum16 = cum & 0xFFFFu;
+    freq16 = exists ? freq & 0xFFFFu : 0u;
+    cum16 = exists ? cum & 0xFFFFu : 0u;
 }
 
 __device__ inline RansEncEntry make_enc_entry(uint32_t f, uint32_t c) {
@@ -152,13 +157,13 @@ __device__ inline uint32_t build_dec_slots(uint32_t f, uint32_t c, uint32_t* scr
 }
 
 __global__ __launch_bounds__(256) void rans_table_kernel(const uint32_t* __restrict__ hist,
-                                                         RansTable* __restrict__ tables) {
+                                                         RansTable* __restrict__ tables, uint32_t n_sym) {
     __shared__ uint32_t scratch[768];
     const int chain = blockIdx.x;
     const int s = threadIdx.x;
-    const uint32_t count = hist[(size_t)chain * 256 + s];
+    const uint32_t count = (uint32_t)s < n_sym ? hist[(size_t)chain * 256 + s] : 0u;
     uint32_t f, c;
-    freq_table_256(count, scratch, f, c);
+    freq_table_256(count, n_sym, scratch, f, c);
     tables[chain].enc[s] = make_enc_entry(f, c);
     uint32_t fl = build_dec_slots(f, c, scratch, &tables[chain].dec);
     if (count > 0u && f == 0u) fl |= kTableDiverges;
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                                                          unsigned long long group_head,
                                                          unsigned n_split,
                                                          RansResult* __restrict__ results,
-                                                         unsigned long long cap1, unsigned long long cap2) {
+                                                         unsigned long long cap1, unsigned long long cap2,
+                                                         uint32_t x_init, uint32_t keep_open) {
     __shared__ uint4 tab_a[256];  // xmax, xmax8, rcp, rsh
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
     __shared__ __attribute__((aligned(16))) uint8_t tile[kEncTile];
@@ -304,8 +310,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         tab_b[s] = make_uint4((uint32_t)e.g, e.cbias, e.freq, e.cum);
     }
 
-    const bool table_clean = (tbl->flags & (kTableVerified | kTableNeedsGeneric | kTableDiverges)) == kTableVerified;  // uniform
-    uint32_t x = kRansL;  // RansEncoder::new, src/rans.rs:249-254
+    // (a state carried in from an earlier call may lie outside the range the one-compare step assumes)
+    const bool table_clean = x_init == kRansL && (tbl->flags & (kTableVerified | kTableNeedsGeneric | kTableDiverges)) == kTableVerified;  // uniform
+    uint32_t x = x_init;  // RansEncoder::new, src/rans.rs:249-254: 2^23; a continued encoder (:288-294) brings its state
     const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
     unsigned long long written = 0ull;
     uint32_t flags = 0u;
@@ -458,13 +465,16 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         }
     }
 
-    // finish (src/rans.rs:298-308): push the 4 state bytes LSB first; the reversal is implicit
-    if (written + 4ull + 64ull <= cap) {
-        if (lane < 4) out_end[-1 - (long long)(written + lane)] = (uint8_t)((x >> (8 * lane)) & 0xFFu);
-    } else {
-        flags |= kRansOverflow;
+    // finish (src/rans.rs:298-308): push the 4 state bytes LSB first; the reversal is implicit.  keep_open: the encoder
+    // object lives on (more encode / encode_symbols calls follow): the state goes back to the host instead.
+    if (!keep_open) {
+        if (written + 4ull + 64ull <= cap) {
+            if (lane < 4) out_end[-1 - (long long)(written + lane)] = (uint8_t)((x >> (8 * lane)) & 0xFFu);
+        } else {
+            flags |= kRansOverflow;
+        }
+        written += 4ull;
     }
-    written += 4ull;
     if (lane == 0) {
         results[chain].len = written;
         results[chain].flags = flags;
@@ -567,11 +577,14 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         one_owner = __ballot(!same) == 0ull;
     }
 
-    // RansDecoder::new (src/rans.rs:330-347)
+    // RansDecoder::new (src/rans.rs:330-347); a decoder object that has decoded before resumes from its state
+    // (decode / decode_n continue, :351-381)
     uint32_t x = 0u;
     unsigned long long pos = 0ull;
     const unsigned long long len = d.in_len;
-    if (len >= 4ull) {
+    if (d.resume) {
+        x = d.x0; pos = d.pos0;
+    } else if (len >= 4ull) {
         x = ((uint32_t)d.in[0] << 24) | ((uint32_t)d.in[1] << 16) | ((uint32_t)d.in[2] << 8) | (uint32_t)d.in[3];
         pos = 4ull;
     }
@@ -727,6 +740,11 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         for (uint32_t i = lane; i < got; i += 64) d.out[done + i] = obuf[i];
         done += got;
     }
+    // the reference renormalises right after every symbol (src/rans.rs:365-368): settle what the exact loop still owes,
+    // so that the reported state and position are the decoder object's
+    if (pending) {
+        while (x < kRansL && pos < len) { x = (x << 8) | (uint32_t)d.in[pos]; pos += 1ull; }
+    }
     if (lane == 0) {
         results[blockIdx.x].len = pos;
         results[blockIdx.x].flags = flags;
@@ -745,9 +763,9 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
 // launchers
 // ----------------------------------------------------------------------------------
 
-void launch_rans_table(const uint32_t* d_hist, RansTable* d_tables, int n_chains, hipStream_t st) {
+void launch_rans_table(const uint32_t* d_hist, RansTable* d_tables, int n_chains, hipStream_t st, uint32_t n_symbols) {
     if (n_chains <= 0) return;
-    hipLaunchKernelGGL(rans_table_kernel, dim3(n_chains), dim3(256), 0, st, d_hist, d_tables);
+    hipLaunchKernelGGL(rans_table_kernel, dim3(n_chains), dim3(256), 0, st, d_hist, d_tables, n_symbols);
 }
 
 void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq, RansTable* d_table,
@@ -767,21 +785,59 @@ static unsigned chain_lds_pad(int n_chains, unsigned static_lds) {
     return want > static_lds ? want - static_lds : 0u;
 }
 
+// The placement above rests on two things the compiler decides: that the empty AGPR clobber counts towards the kernel's
+// register allocation, and how much static LDS the kernels use.  Both are read back from the runtime here (once), so a
+// compiler update or a kernel edit that breaks either shows up as a failed check instead of a slower headline number.
+struct ChainKernelFacts { bool ok; unsigned enc_regs, enc_lds, enc_wg_per_cu, dec_regs, dec_lds, dec_wg_per_cu, enc_lds_plain, dec_lds_plain; };
+static const ChainKernelFacts& chain_kernel_facts() {
+    static const ChainKernelFacts f = [] {
+        ChainKernelFacts r{};
+        hipFuncAttributes a{};
+        int nb = 0;
+        r.ok = true;
+        auto q = [&](const void* fn, unsigned& regs, unsigned& lds, unsigned* wg) {
+            if (hipFuncGetAttributes(&a, fn) != hipSuccess) { r.ok = false; (void)hipGetLastError(); return; }
+            regs = (unsigned)a.numRegs; lds = (unsigned)a.sharedSizeBytes;
+            if (wg) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, 0) != hipSuccess) { r.ok = false; (void)hipGetLastError(); return; }
+                *wg = (unsigned)nb;
+            }
+        };
+        unsigned dummy = 0;
+        q((const void*)rans_encode_kernel<true>, r.enc_regs, r.enc_lds, &r.enc_wg_per_cu);
+        q((const void*)rans_decode_kernel<true>, r.dec_regs, r.dec_lds, &r.dec_wg_per_cu);
+        q((const void*)rans_encode_kernel<false>, dummy, r.enc_lds_plain, nullptr);
+        q((const void*)rans_decode_kernel<false>, dummy, r.dec_lds_plain, nullptr);
+        return r;
+    }();
+    return f;
+}
+bool chain_kernel_occupancy(uint32_t out[6]) {
+    const ChainKernelFacts& f = chain_kernel_facts();
+    out[0] = f.enc_regs; out[1] = f.enc_lds; out[2] = f.enc_wg_per_cu;
+    out[3] = f.dec_regs; out[4] = f.dec_lds; out[5] = f.dec_wg_per_cu;
+    return f.ok;
+}
+
 void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, const RansTable* d_tables,
                         uint8_t* d_out, uint64_t cap, RansResult* d_results, int n_chains, hipStream_t st,
-                        uint64_t group_stride, uint64_t group_head, unsigned n_split, uint64_t cap_co, uint64_t cap_cg) {
+                        uint64_t group_stride, uint64_t group_head, unsigned n_split, uint64_t cap_co, uint64_t cap_cg,
+                        uint32_t x_init, bool keep_open) {
     if (n_chains <= 0) return;
     auto kern = n_chains <= 1024 ? rans_encode_kernel<true> : rans_encode_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, 9216u), st, d_sym,
+    const ChainKernelFacts& facts = chain_kernel_facts();   // real static LDS of the plain instance (9216 if the query failed)
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, facts.ok ? facts.enc_lds_plain : 9216u), st, d_sym,
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
                        (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, n_split,
-                       d_results, (unsigned long long)(cap_co ? cap_co : cap), (unsigned long long)(cap_cg ? cap_cg : cap));
+                       d_results, (unsigned long long)(cap_co ? cap_co : cap), (unsigned long long)(cap_cg ? cap_cg : cap),
+                       x_init, keep_open ? 1u : 0u);
 }
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {
     if (n_chains <= 0) return;
     auto kern = n_chains <= 1024 ? rans_decode_kernel<true> : rans_decode_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, 21776u + 256u), st, d_descs, d_results);
+    const ChainKernelFacts& facts = chain_kernel_facts();
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, facts.ok ? facts.dec_lds_plain : 21776u + 256u), st, d_descs, d_results);
 }
 
 }  // namespace alice

@@ -1,21 +1,22 @@
 // Pipeline-specialised transform kernels for gfx950: RGB <-> u8 symbols.
 //
-// Forward (FrameEncoder::encode, reference src/pipeline.rs:429-477):
-//   fwd_xy_kernel : per frame and 128x40 tile.  Stage A: a thread owns a 16-pixel row segment
+// Forward (FrameEncoder::encode, reference src/pipeline.rs:429-477), two roles per launch (fwd_band_kernel):
+//   tile role     : per frame and 128x40 tile.  Stage A: a thread owns a 16-pixel row segment
 //                   (+ one halo sample per lifting step on each side): RGB -> YCoCg-R
 //                   (src/color.rs:221-228), edge-replicated padding by index clamping
 //                   (src/pipeline.rs:77-114), row lifting entirely in registers
 //                   (src/wavelet.rs:401-405).  The tile goes through LDS once (the transpose).
 //                   Stage B: a thread owns one column of the tile (+halo rows) in registers, column
-//                   lifting (:408-417), i16 store to the [L|H]-deinterleaved plane.
-//   fwd_t_kernel  : temporal lifting as a stream over frame pairs with a five-value window per
+//                   lifting (:408-417), i16 store to the band slot.
+//   temporal role : temporal lifting as a stream over frame pairs with a five-value window per
 //                   pixel (src/wavelet.rs:421-437), 4 pixels per thread (8-byte loads, 4-byte stores),
 //                   fused Quantizer::quantize (src/quant.rs:89-97), to_symbols (:555-560) and
 //                   build_histogram (:594-600).  Any frame count.
-// Inverse (FrameDecoder::decode, src/pipeline.rs:588-621) mirrors it:
-//   inv_t_kernel  : from_symbols, dequantize, inverse temporal lifting (stream over pairs).
-//   inv_xy_kernel : stage A inverse column lifting (registers) -> LDS -> stage B inverse row lifting,
+// Inverse (FrameDecoder::decode, src/pipeline.rs:588-621) mirrors it (inv_band_kernel):
+//   temporal role : from_symbols, dequantize, inverse temporal lifting (stream over pairs).
+//   tile role     : stage A inverse column lifting (registers) -> LDS -> stage B inverse row lifting,
 //                   `as i16`, ycocg_r_to_rgb_bytes.
+// How the roles of consecutive bands share launches: "Band-ordered, role-fused launches" below.
 //
 // Lifting facts used: inside one lifting step every write depends only on samples of the other
 // parity, so a step is data-parallel; an output depends on inputs within +-n_steps samples;
@@ -25,6 +26,7 @@
 // Intermediates: the forward path stores i16 (from u8 input every value in the transform stays
 // below 2^13 in magnitude, SURVEY.md section 7 hard part 5); the inverse path stores i32 because a
 // desynchronised decoder feeds it arbitrary symbols (i16 when the host proves the bound).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -52,7 +54,6 @@ __device__ __forceinline__ int lift_delta(int a, int b, int c) {
 __device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 
 struct Coeffs { int c[4]; };
-struct TileMap { int nx, ny, ix0, ix1, iy0, iy1; };
 
 // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an
 // L2), while neighbouring tiles share halo rows/columns and 128-byte lines.  Launch a 1-D grid padded
@@ -66,27 +67,6 @@ __device__ __forceinline__ unsigned xcd_logical_block(unsigned total) {
     return l < total ? l : 0xFFFFFFFFu;
 }
 static inline unsigned xcd_grid(unsigned long long total) { return (unsigned)(((total + 7) / 8) * 8); }
-
-// Which tile this workgroup takes.  An interior launch (EDGE = false) covers the rectangle of tiles [ix0, ix1) x
-// [iy0, iy1) whose halo lies inside the frame; a border launch (EDGE = true) one linear sequence over the four strips
-// around it (top, bottom, left, right).  `frames` frames, XCD-aware order (xcd_logical_block).  False: nothing to do.
-template <bool EDGE>
-__device__ __forceinline__ bool tile_of_block(const TileMap& tm, unsigned frames, int& bx, int& by, int& t) {
-    const int n_top = tm.nx * tm.iy0, n_bot = tm.nx * (tm.ny - tm.iy1), n_left = tm.ix0 * (tm.iy1 - tm.iy0);
-    const int n_right = (tm.nx - tm.ix1) * (tm.iy1 - tm.iy0);
-    const int iw = tm.ix1 - tm.ix0, ih = tm.iy1 - tm.iy0;
-    const unsigned per_frame = EDGE ? (unsigned)(n_top + n_bot + n_left + n_right) : (unsigned)(iw * ih);
-    const unsigned l = xcd_logical_block(per_frame * frames);
-    if (l == 0xFFFFFFFFu) return false;
-    t = (int)(l / per_frame);
-    int i = (int)(l % per_frame);
-    if (!EDGE) { bx = tm.ix0 + i % iw; by = tm.iy0 + i / iw; }
-    else if (i < n_top) { bx = i % tm.nx; by = i / tm.nx; }
-    else if ((i -= n_top) < n_bot) { bx = i % tm.nx; by = tm.iy1 + i / tm.nx; }
-    else if ((i -= n_bot) < n_left) { bx = i % tm.ix0; by = tm.iy0 + i / tm.ix0; }
-    else { i -= n_left; const int wr = tm.nx - tm.ix1; bx = tm.ix1 + i % wr; by = tm.iy0 + i / wr; }
-    return true;
-}
 
 // Whole-sample symmetric extension of an even-length signal: x[-k] = x[k], x[n-1+k] = x[n-1-k].
 // The reference mirrors one neighbour at the two ends of every lifting step (src/wavelet.rs:186-190,
@@ -130,25 +110,76 @@ __device__ __forceinline__ void lift_regs(int (&v)[N], const Coeffs& cf) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: forward spatial transform of one frame tile
+// Band-ordered, role-fused launches (round 3)
+//
+// The spatial (tile) kernels are bound by instruction issue, the temporal kernels by memory, and between them sits
+// the i16 intermediate: 6 B/px written once and read once, 796 MB per 1080p x 64 chunk -- three times the 256 MiB
+// Infinity Cache.  So a chunk is cut into BANDS of whole tile rows (all frames of those rows), small enough for the
+// band's intermediate to stay on the die between its producer and its consumer, and every launch carries TWO roles:
+//     forward   launch j = { temporal pass of band j-1 (memory)  ||  tile pass of band j (issue) }
+//     inverse   launch j = { temporal pass of band j   (memory)  ||  tile pass of band j-1 (issue) }
+// The roles of one launch touch different band slots of a two-slot ring, so stream order between launches is the only
+// synchronisation; the temporal role's workgroups come first in the grid (they are few and long-running and start at
+// once), the tile role's workgroups stream through the remaining slots of every CU.  The last role of a chunk stays
+// pending and is fused with the first launch of the next chunk (ForwardPipe / InversePipe), so a batch never drains.
+// A band's rows are [low-band rows | high-band rows] of the y-deinterleaved plane; inside the band slot they are
+// contiguous, so the temporal role reads (writes) the slot linearly and maps a pixel to its place in the symbol plane
+// through two segment bases.  The inverse band carries two halo rows of each half on either side (the temporal pass
+// simply covers them: it is per pixel), so its tile role depends on its own band only.
+// Shapes that cannot be cut (a padded width that is not a multiple of 4: a segment would not be a whole number of
+// 4-pixel groups) run as ONE band = the whole frame, where both mappings are the identity.
+// ------------------------------------------------------------------------------------------------
+
+// one band of a chunk as the tile role sees it
+struct BandTiles {
+    int nx, by0, nby;            // tiles per tile row; first tile row of the band, tile rows in it
+    int ix0, ix1, iy0, iy1;      // the interior rectangle of the FRAME in tile coordinates (halo inside the frame)
+};
+
+// logical block of the tile role -> tile.  XCD-aware order: the role's blocks start at a multiple of 8 and are padded to
+// a multiple of 8, so (b & 7) is still the XCD and XCD k takes the k-th contiguous eighth of the sequence
+// (frame-major, then tile row, then tile).
+__device__ __forceinline__ bool band_tile_of_block(const BandTiles& bt, unsigned frames, unsigned role_block, unsigned role_blocks,
+                                                   int& bx, int& by, int& t, bool& edge) {
+    const unsigned per_xcd = role_blocks >> 3;
+    const unsigned l = (role_block & 7u) * per_xcd + (role_block >> 3);
+    const unsigned per_frame = (unsigned)(bt.nx * bt.nby);
+    if (l >= per_frame * frames) return false;
+    t = (int)(l / per_frame);
+    const int i = (int)(l % per_frame);
+    bx = i % bt.nx; by = bt.by0 + i / bt.nx;
+    edge = !(bx >= bt.ix0 && bx < bt.ix1 && by >= bt.iy0 && by < bt.iy1);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: forward spatial transform of one frame tile (tile role of the forward launch)
 // ------------------------------------------------------------------------------------------------
 constexpr int F_TW = 128, F_TH = 40, F_SEG = 16, F_NSEG = 8, F_THREADS = 384;
 constexpr int F_LP = F_TW / 2 + 1;  // LDS row pitch in dwords (packed i16 pairs); odd pitch keeps stage-A stores at <= 2-way conflicts
 
-template <int NS, bool EDGE>
-__global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __restrict__ rgb, int16_t* __restrict__ mid,
-                                                                  ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
-    // interior launch: a rectangle of tiles at (ix0, iy0); border launch: one linear grid over the
-    // four border strips (top, bottom, left, right of the interior rectangle)
+struct FwdXy {
+    const uint8_t* rgb;
+    int16_t* mid;                // the band's slot: i16 [ch][t][band row][pw], band rows = [low rows | high rows]
+    ChunkDims d;
+    Coeffs cf;
+    int aligned;
+    BandTiles bt;
+    int y0, rows;                // the band: first padded row (even) and number of padded rows (even)
+};
+
+// PROBE (VALU-floor measurement, alice_codec_test_transform_ms): the same instruction stream with every global load
+// replaced by a register expression and every global store by an XOR into a checksum that is (never) stored at the end.
+template <int NS, bool EDGE, int PROBE = 0>
+__device__ __forceinline__ void fwd_xy_tile(const FwdXy& a, int bx, int by, int t, int* lds) {
     constexpr int H = NS;
     constexpr int ER = F_TH + 2 * H;
     constexpr int SE = F_SEG + 8;
     constexpr int K0 = 4 - H;
     constexpr int NL = F_SEG + 2 * H;
-    extern __shared__ int lds[];
+    const ChunkDims& d = a.d;
+    const Coeffs& cf = a.cf;
     const int tid = threadIdx.x;
-    int bx, by, t;
-    if (!tile_of_block<EDGE>(tm, (unsigned)d.pf, bx, by, t)) return;
     const int gx0 = bx * F_TW, gy0 = by * F_TH;
     const int pw = d.pw, ph = d.ph;
     const int st = min(t, (int)d.f - 1);
@@ -161,13 +192,13 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
             // of an odd size (src/pipeline.rs:77-114: edge replicate) clamps to the last real one
             const int sy = EDGE ? min(reflect_idx(gy, ph), (int)d.h - 1) : gy;
             const int gxs = gx0 - 4 + s * F_SEG;
-            const uint8_t* row = rgb + ((size_t)st * d.h + sy) * d.w * 3;
+            const uint8_t* row = a.rgb + ((size_t)st * d.h + sy) * d.w * 3;
             int y[SE], co[SE], cg[SE];
-            if (aligned && (!EDGE || (gxs >= 0 && gxs + SE <= (int)d.w))) {
+            if ((PROBE & 1) || (a.aligned && (!EDGE || (gxs >= 0 && gxs + SE <= (int)d.w)))) {
                 const uint32_t* p4 = (const uint32_t*)(row + (ptrdiff_t)gxs * 3);
                 uint32_t wd[18];
 #pragma unroll
-                for (int i = 0; i < 18; ++i) wd[i] = p4[i];
+                for (int i = 0; i < 18; ++i) wd[i] = (PROBE & 1) ? ((uint32_t)tid * 0x9E3779B1u + (uint32_t)(i + t) * 0x85EBCA6Bu) : p4[i];
 #pragma unroll
                 for (int k = 0; k < SE; ++k) {
                     const int b0 = 3 * k;
@@ -220,7 +251,7 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
         const int xq = tid & 127, ch = tid >> 7;
         const int par = xq >> 6, j = xq & 63;
         const int gxp = gx0 / 2 + j;
-        const int hw = pw / 2, hh = ph / 2;
+        const int hw = pw / 2, hr = a.rows / 2;
         if (!EDGE || gxp < hw) {
             int v[ER];
             const int* L = lds + (ch * ER) * F_LP + (xq >> 1);
@@ -228,15 +259,19 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
 #pragma unroll
             for (int r = 0; r < ER; ++r) v[r] = (int)(short)(L[r * F_LP] >> sh);
             lift_regs<ER, NS, false, false>(v, cf);
-            int16_t* out = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + gxp;
+            // band slot: frame plane = rows x pw, low rows of the band first, then its high rows
+            int16_t* out = a.mid + ((size_t)ch * d.pf + t) * ((size_t)a.rows * pw) + (size_t)par * hw + gxp;
+            const int ly0 = (gy0 - a.y0) >> 1;   // gy0 and y0 are even
+            int acc = 0;
 #pragma unroll
             for (int k = 0; k < F_TH; ++k) {
-                const int gy = gy0 + k;
-                if (!EDGE || gy < ph) {
-                    const int yy = (gy & 1) * hh + (gy >> 1);
-                    out[(size_t)yy * pw] = (int16_t)v[H + k];
+                if (!EDGE || gy0 + k < ph) {
+                    const int yy = (k & 1) * hr + ly0 + (k >> 1);
+                    if (PROBE & 2) acc ^= v[H + k] + yy;
+                    else out[(size_t)yy * pw] = (int16_t)v[H + k];
                 }
             }
+            if ((PROBE & 2) && acc == 0x5EEDF00D) out[0] = (int16_t)acc;
         }
     }
 }
@@ -244,16 +279,10 @@ __global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(const uint8_t* __rest
 
 // ------------------------------------------------------------------------------------------------
 // K2: forward temporal lifting (stream over frame pairs) + quantise + symbols + histogram
+//     (temporal role of the forward launch)
 // ------------------------------------------------------------------------------------------------
 struct I4 { int v[4]; };
 
-__device__ __forceinline__ I4 load4_i16(const int16_t* p) {
-    const uint2 w = *(const uint2*)p;
-    I4 r;
-    r.v[0] = (int)(short)(w.x & 0xFFFF); r.v[1] = (int)(short)(w.x >> 16);
-    r.v[2] = (int)(short)(w.y & 0xFFFF); r.v[3] = (int)(short)(w.y >> 16);
-    return r;
-}
 template <bool EXACT>
 __device__ __forceinline__ I4 lift4(const I4& base, const I4& a, const I4& b, int c) {
     I4 r;
@@ -308,28 +337,36 @@ __device__ __forceinline__ I4 unpack4_i16(const uint2 w) {
 // between ticks is O1[k], E1[k], O2[k-1] plus the raw pairs in flight: five values per pixel.
 // The tick is instantiated per position in a 4-tick block so that every register role is static: no window
 // shuffling moves, no per-tick selects except the end-of-signal mirror.
-template <int NS, bool STEP1, bool HIST>
+template <int NS, bool STEP1, bool HIST, int PROBE = 0>
 struct FwdT {
-    const char* src;     // channel base (uniform)
-    char* dst;
-    size_t plane;
-    uint32_t off16, off8;  // this thread's byte offset inside an i16 / u8 frame
+    const char* src;     // channel base inside the band slot (uniform)
+    char* dst;           // channel base of the symbol volume (uniform)
+    size_t plane_s;      // pixels per frame of the band slot
+    size_t plane_d;      // pixels per frame of the symbol volume
+    uint32_t off16, off8;  // this thread's byte offset inside an i16 slot frame / a u8 symbol frame
     int half;
     Coeffs cf;
     uint32_t hdz, magic, lane_rep;
     uint32_t* lh;
     I4 o1p, e1p, o2pp;
+    uint32_t acc;        // PROBE only
 
     __device__ __forceinline__ void load_pair(int pair, uint2& e, uint2& o) const {
-        const char* fe = src + (size_t)(2 * pair) * plane * 2;
+        if (PROBE & 1) {     // small 16-bit pairs made of the pair index and the pixel offset: no memory
+            const uint32_t m = (off16 + (uint32_t)pair * 0x00130017u) & 0x03FF03FFu;
+            e = make_uint2(m, m ^ 0x00550033u); o = make_uint2(m + 0x00010002u, m ^ 0x000F00F0u);
+            return;
+        }
+        const char* fe = src + (size_t)(2 * pair) * plane_s * 2;
         e = *(const uint2*)(fe + off16);
-        o = *(const uint2*)(fe + plane * 2 + off16);
+        o = *(const uint2*)(fe + plane_s * 2 + off16);
     }
-    __device__ __forceinline__ void emit(int frame, const I4& lo, const I4& hi) const {
+    __device__ __forceinline__ void emit(int frame, const I4& lo, const I4& hi) {
         const uint32_t a = quant_sym4<STEP1, HIST>(lo, hdz, magic, lh, lane_rep);
         const uint32_t b = quant_sym4<STEP1, HIST>(hi, hdz, magic, lh, lane_rep);
-        *(uint32_t*)(dst + (size_t)frame * plane + off8) = a;
-        *(uint32_t*)(dst + (size_t)(half + frame) * plane + off8) = b;
+        if (PROBE & 2) { acc ^= a + (uint32_t)frame; acc ^= b; return; }
+        *(uint32_t*)(dst + (size_t)frame * plane_d + off8) = a;
+        *(uint32_t*)(dst + (size_t)(half + frame) * plane_d + off8) = b;
     }
     // FIRST: k == 0, SECOND: k == 1 (the left mirrors); en = E0[k+1] or, on the last pair, E0[k] itself
     template <bool FIRST, bool SECOND>
@@ -353,49 +390,30 @@ struct FwdT {
         const I4 e2 = lift4<false>(e1p, half == 1 ? o2 : o2pp, o2, cf.c[3]);
         emit(half - 1, e2, o2);
     }
-};
-
-template <int NS, bool STEP1, bool HIST>
-__global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ mid, uint8_t* __restrict__ sym,
-                                                    uint32_t* __restrict__ hist, ChunkDims d, Coeffs cf, int step,
-                                                    uint32_t magic) {
-    __shared__ uint32_t lh[HIST ? kHistWords : 1];
-    const int tid = threadIdx.x;
-    if (HIST) {
-        for (int i = tid; i < kHistWords; i += 256) lh[i] = 0u;
-        __syncthreads();
-    }
-    const size_t plane = (size_t)d.pw * d.ph;
-    const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
-    const int ch = blockIdx.y;
-    const int half = (int)d.pf / 2;
-    if (idx < plane) {
-        FwdT<NS, STEP1, HIST> f;
-        f.src = (const char*)(mid + (size_t)ch * d.pf * plane);
-        f.dst = (char*)(sym + (size_t)ch * d.pf * plane);
-        f.plane = plane; f.off16 = (uint32_t)idx * 2u; f.off8 = (uint32_t)idx;
-        f.half = half; f.cf = cf; f.hdz = (uint32_t)step / 2u; f.magic = magic; f.lane_rep = (uint32_t)tid & 31u; f.lh = lh;
-        f.o1p = I4{}; f.e1p = I4{}; f.o2pp = I4{};
+    // the whole stream of one 4-pixel group
+    __device__ __forceinline__ void run() {
+        o1p = I4{}; e1p = I4{}; o2pp = I4{};
+        acc = 0u;
         uint2 re[4], ro[4];   // raw pairs in flight; slot = pair & 3, always a compile-time index below
 #pragma unroll
         for (int i = 0; i < 4; ++i) { re[i] = make_uint2(0u, 0u); ro[i] = make_uint2(0u, 0u); }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (i < half) f.load_pair(i, re[i], ro[i]);
+            if (i < half) load_pair(i, re[i], ro[i]);
         I4 ce = unpack4_i16(re[0]), co = unpack4_i16(ro[0]);
         // block 0: the two left mirrors are static; block ends may fall anywhere (short signals)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (u < half) {
-                if (u + 3 < half) f.load_pair(u + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
+                if (u + 3 < half) load_pair(u + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
                 const I4 ne = unpack4_i16(re[(u + 1) & 3]);
                 const bool last = u == half - 1;
                 I4 en;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) en.v[i] = last ? ce.v[i] : ne.v[i];
-                if (u == 0) f.template tick<true, false>(u, ce, co, en);
-                else if (u == 1) f.template tick<false, true>(u, ce, co, en);
-                else f.template tick<false, false>(u, ce, co, en);
+                if (u == 0) tick<true, false>(u, ce, co, en);
+                else if (u == 1) tick<false, true>(u, ce, co, en);
+                else tick<false, false>(u, ce, co, en);
                 ce = ne; co = unpack4_i16(ro[(u + 1) & 3]);
             }
         }
@@ -405,9 +423,9 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = kb + u;
-                if (k + 3 < half) f.load_pair(k + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
+                if (k + 3 < half) load_pair(k + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
                 const I4 ne = unpack4_i16(re[(u + 1) & 3]);
-                f.template tick<false, false>(k, ce, co, ne);
+                tick<false, false>(k, ce, co, ne);
                 ce = ne; co = unpack4_i16(ro[(u + 1) & 3]);
             }
         }
@@ -417,30 +435,105 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(const int16_t* __restrict__ 
             for (int u = 0; u < 4; ++u) {
                 const int k = kb + u;
                 if (k < half) {
-                    if (k + 3 < half) f.load_pair(k + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
+                    if (k + 3 < half) load_pair(k + 3, re[(u + 3) & 3], ro[(u + 3) & 3]);
                     const I4 ne = unpack4_i16(re[(u + 1) & 3]);
                     const bool last = k == half - 1;
                     I4 en;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) en.v[i] = last ? ce.v[i] : ne.v[i];
-                    f.template tick<false, false>(k, ce, co, en);
+                    tick<false, false>(k, ce, co, en);
                     ce = ne; co = unpack4_i16(ro[(u + 1) & 3]);
                 }
             }
         }
-        f.flush();
+        flush();
+        if ((PROBE & 2) && acc == 0x5EEDF00Du) *(uint32_t*)(dst + off8) = acc;
     }
-    if (!HIST) return;
+};
+
+// The temporal role's view of a band.  A unit is one workgroup's worth of 4-pixel groups of one channel; a role
+// workgroup takes units rb, rb + n_blocks, ... (units are channel-major, so it changes channel at most twice).
+struct BandT {
+    uint32_t pf;                 // padded frames
+    uint32_t band_px;            // pixels of the band per frame = rows * pw (a multiple of 4)
+    uint32_t seg_px;             // pixels of its low-row half; the rest are the high rows
+    uint32_t lo_base, hi_base;   // where those halves start inside a frame of the chunk's (deinterleaved) plane
+    uint64_t plane;              // pw * ph
+    uint32_t units_per_ch, n_blocks;
+};
+// pixel index of a slot-linear pixel inside the chunk's plane (identity when the band is the whole frame)
+__device__ __forceinline__ uint32_t band_plane_index(const BandT& b, uint32_t idx) {
+    return idx < b.seg_px ? b.lo_base + idx : b.hi_base + (idx - b.seg_px);
+}
+
+struct FwdTm {
+    const int16_t* mid;
+    uint8_t* sym;
+    uint32_t* hist;
+    Coeffs cf;
+    uint32_t hdz, magic;
+    BandT b;
+};
+
+template <int NS, bool STEP1, int THREADS, int PROBE = 0>
+__device__ __forceinline__ void fwd_t_role(const FwdTm& a, unsigned rb, uint32_t* lh) {
+    const int tid = threadIdx.x;
+    if (rb >= a.b.n_blocks) return;
+    for (int i = tid; i < kHistWords; i += THREADS) lh[i] = 0u;
     __syncthreads();
-    // fold the replicas of bin `tid` (rotated start: the 256 threads read 32 different banks)
-    uint32_t cnt = 0u;
+    int cur_ch = -1;
+    auto fold = [&](int ch) {
+        __syncthreads();
+        if (tid < 256) {
+            // fold the replicas of bin `tid` (rotated start: the threads read 32 different banks)
+            uint32_t cnt = 0u;
 #pragma unroll 8
-    for (int r = 0; r < kHistReplicas; ++r) cnt += lh[tid * kHistReplicas + ((r + tid) & (kHistReplicas - 1))];
-    if (cnt) atomicAdd(&hist[ch * 256 + tid], cnt);
+            for (int r = 0; r < kHistReplicas; ++r) cnt += lh[tid * kHistReplicas + ((r + tid) & (kHistReplicas - 1))];
+            if (cnt) atomicAdd(&a.hist[ch * 256 + tid], cnt);
+        }
+    };
+    for (uint32_t unit = rb; unit < 3u * a.b.units_per_ch; unit += a.b.n_blocks) {
+        const int ch = (int)(unit / a.b.units_per_ch);
+        const uint32_t blk = unit % a.b.units_per_ch;
+        if (ch != cur_ch && cur_ch >= 0) {       // uniform per workgroup
+            fold(cur_ch);
+            __syncthreads();
+            for (int i = tid; i < kHistWords; i += THREADS) lh[i] = 0u;
+            __syncthreads();
+        }
+        cur_ch = ch;
+        const uint32_t idx = (blk * (uint32_t)THREADS + (uint32_t)tid) * 4u;
+        if (idx < a.b.band_px) {
+            FwdT<NS, STEP1, true, PROBE> f;
+            f.src = (const char*)(a.mid + (size_t)ch * a.b.pf * a.b.band_px);
+            f.dst = (char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
+            f.plane_s = a.b.band_px; f.plane_d = a.b.plane;
+            f.off16 = idx * 2u; f.off8 = band_plane_index(a.b, idx);
+            f.half = (int)a.b.pf / 2; f.cf = a.cf; f.hdz = a.hdz; f.magic = a.magic; f.lane_rep = (uint32_t)tid & 31u; f.lh = lh;
+            f.run();
+        }
+    }
+    if (cur_ch >= 0) fold(cur_ch);
+}
+
+// the forward launch: temporal role of the previous band in blocks [0, n_t), tile role of this band behind them
+template <int NS, bool STEP1, int PROBE = 0>
+__global__ __launch_bounds__(F_THREADS) void fwd_band_kernel(FwdXy xa, FwdTm ta, unsigned n_t) {
+    extern __shared__ int lds[];
+    const unsigned b = blockIdx.x;
+    if (b < n_t) { fwd_t_role<NS, STEP1, F_THREADS, PROBE>(ta, b, (uint32_t*)lds); return; }
+    int bx, by, t;
+    bool edge;
+    if (!band_tile_of_block(xa.bt, (unsigned)xa.d.pf, b - n_t, gridDim.x - n_t, bx, by, t, edge)) return;
+    // (border tiles need the clamping index map whenever the loads are real; with the loads replaced the interior
+    // instance serves every tile)
+    if (edge && !(PROBE & 1)) fwd_xy_tile<NS, true, PROBE>(xa, bx, by, t, lds);
+    else fwd_xy_tile<NS, false, PROBE>(xa, bx, by, t, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: from_symbols + dequantize + inverse temporal lifting (stream over pairs); frames t < f only
+//     (temporal role of the inverse launch)
 // ------------------------------------------------------------------------------------------------
 template <typename MidT>
 __device__ __forceinline__ void store4(MidT* p, const I4& x);
@@ -462,20 +555,23 @@ __device__ __forceinline__ void store4<int16_t>(int16_t* p, const I4& x) {
 // Tick k consumes the symbols of frames k (low band) and half+k (high band), emits frame 2(k-1) and
 // frame 2(k-2)+1.  from_symbols + dequantize (src/quant.rs:104-110,581-587) is a 256-entry table in LDS:
 // one byte extract and one LDS read per sample instead of seven VALU operations.
-template <int NS, bool EXACT, typename MidT>
+template <int NS, bool EXACT, typename MidT, int PROBE = 0>
 struct InvT {
-    const char* src;
-    MidT* dst;            // channel base + this thread's pixel offset
-    size_t plane;
+    const char* src;      // channel base of the symbol volume
+    MidT* dst;            // channel base inside the band slot + this thread's slot pixel
+    size_t plane_s;       // pixels per frame of the symbol volume
+    size_t plane_d;       // pixels per frame of the band slot
     uint32_t off8;
     int half, nf;
     int c0, c1, c2, c3;   // already negated
     const int* lut;
     I4 o2p, e1p, o1pp, e0pp;
+    int acc;              // PROBE only
 
     __device__ __forceinline__ void load_pair(int pair, uint32_t& lo, uint32_t& hi) const {
-        lo = *(const uint32_t*)(src + (size_t)pair * plane + off8);
-        hi = *(const uint32_t*)(src + (size_t)(half + pair) * plane + off8);
+        if (PROBE & 1) { lo = (off8 + (uint32_t)pair * 0x01030507u) & 0x0F070F07u; hi = lo ^ 0x01010101u; return; }
+        lo = *(const uint32_t*)(src + (size_t)pair * plane_s + off8);
+        hi = *(const uint32_t*)(src + (size_t)(half + pair) * plane_s + off8);
     }
     __device__ __forceinline__ I4 dq(uint32_t packed) const {
         I4 r;
@@ -483,8 +579,9 @@ struct InvT {
         for (int i = 0; i < 4; ++i) r.v[i] = lut[(packed >> (8 * i)) & 0xFFu];
         return r;
     }
-    __device__ __forceinline__ void put(int frame, const I4& x) const {
-        if (frame < nf) store4<MidT>(dst + (size_t)frame * plane, x);
+    __device__ __forceinline__ void put(int frame, const I4& x) {
+        if (PROBE & 2) { acc ^= (x.v[0] + frame) ^ x.v[1] ^ x.v[2] ^ x.v[3]; return; }
+        if (frame < nf) store4<MidT>(dst + (size_t)frame * plane_d, x);
     }
     template <bool FIRST, bool SECOND>
     __device__ __forceinline__ void tick(int k, uint32_t lo, uint32_t hi) {
@@ -517,135 +614,198 @@ struct InvT {
             put(2 * (half - 1) + 1, lift4<EXACT>(o2p, e1p, e1p, c0));
         }
     }
-};
-
-template <int NS, bool EXACT, typename MidT>
-__global__ __launch_bounds__(256) void inv_t_kernel(const uint8_t* __restrict__ sym, MidT* __restrict__ mid, ChunkDims d,
-                                                    Coeffs cf, int step0, int step1, int step2) {
-    __shared__ int lut[256];
-    const int tid = threadIdx.x;
-    const int ch = blockIdx.y;
-    {
-        const int step = ch == 0 ? step0 : (ch == 1 ? step1 : step2);
-        const int s = tid;
-        const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));  // src/quant.rs:581-587
-        lut[s] = (int)((unsigned)q * (unsigned)step);                      // src/quant.rs:104-110 (wrapping)
-    }
-    __syncthreads();
-    const size_t plane = (size_t)d.pw * d.ph;
-    const size_t idx = ((size_t)blockIdx.x * 256 + tid) * 4;
-    if (idx >= plane) return;
-    const int half = (int)d.pf / 2;
-    InvT<NS, EXACT, MidT> f;
-    f.src = (const char*)(sym + (size_t)ch * d.pf * plane);
-    f.dst = mid + (size_t)ch * d.pf * plane + idx;
-    f.plane = plane; f.off8 = (uint32_t)idx; f.half = half; f.nf = (int)d.f;
-    f.c0 = -cf.c[0]; f.c1 = -cf.c[1]; f.c2 = -cf.c[2]; f.c3 = -cf.c[3];
-    f.lut = lut;
-    f.o2p = I4{}; f.e1p = I4{}; f.o1pp = I4{}; f.e0pp = I4{};
-    uint32_t rl[4] = {0u, 0u, 0u, 0u}, rh[4] = {0u, 0u, 0u, 0u};   // symbols in flight; slot = pair & 3 (static)
+    __device__ __forceinline__ void run() {
+        o2p = I4{}; e1p = I4{}; o1pp = I4{}; e0pp = I4{};
+        acc = 0;
+        uint32_t rl[4] = {0u, 0u, 0u, 0u}, rh[4] = {0u, 0u, 0u, 0u};   // symbols in flight; slot = pair & 3 (static)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (i < half) f.load_pair(i, rl[i], rh[i]);
+        for (int i = 0; i < 3; ++i)
+            if (i < half) load_pair(i, rl[i], rh[i]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (u < half) {
-            if (u + 3 < half) f.load_pair(u + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
-            if (u == 0) f.template tick<true, false>(u, rl[u], rh[u]);
-            else if (u == 1) f.template tick<false, true>(u, rl[u], rh[u]);
-            else f.template tick<false, false>(u, rl[u], rh[u]);
+        for (int u = 0; u < 4; ++u) {
+            if (u < half) {
+                if (u + 3 < half) load_pair(u + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
+                if (u == 0) tick<true, false>(u, rl[u], rh[u]);
+                else if (u == 1) tick<false, true>(u, rl[u], rh[u]);
+                else tick<false, false>(u, rl[u], rh[u]);
+            }
         }
-    }
-    int kb = 4;
-    for (; kb + 4 <= half; kb += 4) {
+        int kb = 4;
+        for (; kb + 4 <= half; kb += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u;
+                if (k + 3 < half) load_pair(k + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
+                tick<false, false>(k, rl[u], rh[u]);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = kb + u;
-            if (k + 3 < half) f.load_pair(k + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
-            f.template tick<false, false>(k, rl[u], rh[u]);
+            if (k < half) {
+                if (k + 3 < half) load_pair(k + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
+                tick<false, false>(k, rl[u], rh[u]);
+            }
         }
+        flush();
+        if ((PROBE & 2) && acc == 0x5EEDF00D) store4<MidT>(dst, o2p);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = kb + u;
-        if (k < half) {
-            if (k + 3 < half) f.load_pair(k + 3, rl[(u + 3) & 3], rh[(u + 3) & 3]);
-            f.template tick<false, false>(k, rl[u], rh[u]);
-        }
+};
+
+struct InvTm {
+    const uint8_t* sym;
+    void* mid;                   // the band's slot: MidT [ch][t][slot row][pw], slot rows = [low rows L0.. | the same high rows]
+    Coeffs cf;
+    int step[3];
+    uint32_t nf;                 // real frames (t < f are written)
+    BandT b;                     // band_px = slot pixels per frame; lo_base / hi_base = L0 * pw / (hh + L0) * pw
+};
+
+template <int NS, bool EXACT, typename MidT, int THREADS, int PROBE = 0>
+__device__ __forceinline__ void inv_t_role(const InvTm& a, unsigned rb, int* luts /* 3 * 256 */) {
+    const int tid = threadIdx.x;
+    if (rb >= a.b.n_blocks) return;
+    for (int i = tid; i < 3 * 256; i += THREADS) {
+        const int s = i & 255;
+        const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));      // src/quant.rs:581-587
+        luts[i] = (int)((unsigned)q * (unsigned)a.step[i >> 8]);              // src/quant.rs:104-110 (wrapping)
     }
-    f.flush();
+    __syncthreads();
+    for (uint32_t unit = rb; unit < 3u * a.b.units_per_ch; unit += a.b.n_blocks) {
+        const int ch = (int)(unit / a.b.units_per_ch);
+        const uint32_t blk = unit % a.b.units_per_ch;
+        const uint32_t idx = (blk * (uint32_t)THREADS + (uint32_t)tid) * 4u;
+        if (idx >= a.b.band_px) continue;
+        InvT<NS, EXACT, MidT, PROBE> f;
+        f.src = (const char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
+        f.dst = (MidT*)a.mid + (size_t)ch * a.b.pf * a.b.band_px + idx;
+        f.plane_s = a.b.plane; f.plane_d = a.b.band_px;
+        f.off8 = band_plane_index(a.b, idx);
+        f.half = (int)a.b.pf / 2; f.nf = (int)a.nf;
+        f.c0 = -a.cf.c[0]; f.c1 = -a.cf.c[1]; f.c2 = -a.cf.c[2]; f.c3 = -a.cf.c[3];
+        f.lut = luts + ch * 256;
+        f.run();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: inverse spatial transform of one frame tile + colour
+// K4: inverse spatial transform of one frame tile + colour (tile role of the inverse launch)
 // ------------------------------------------------------------------------------------------------
 constexpr int I_TW = 96, I_TH = 32, I_SEG = 8, I_NSEG = 12, I_THREADS = 384;
-constexpr int I_HO = 52;    // LDS column of the first odd (high-band) sample of a row: the two halves sit at 0 and 52
-constexpr int I_LW = 108;   // LDS row pitch in dwords: a multiple of 4, so that every 8-sample run stage B reads is two
-                            // aligned ds_read_b128 (conflict-free: 16 lanes x 4 dwords span the 64 banks), and k * 108 + x
-                            // keeps the column-major stores of stage A on 32 different banks
+constexpr int I_HO = 56;    // LDS column of the first odd (high-band) sample of a row: the two halves sit at 0 and 56
+constexpr int I_LW = 112;   // LDS row pitch in dwords.  Every 8-sample run stage B reads is two aligned ds_read_b128.  A b128
+                            // read is served in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...;
+                            // MI355X_MICROARCH.md, LDS), bank = dword mod 64; with 12 lanes per tile row, pitch 112 / halves at 0 and
+                            // 56 is the layout below 128 dwords for which every group touches 64 different banks (pitch 108 / 52,
+                            // chosen in round 2 for contiguous groups, was a 2-way conflict on every read:
+                            // scripts/lds_bank_model.py); column-major stage-A stores stay at most 2-way, which costs nothing
 
-// LDS16: the host proved that every value after the inverse column lifting fits i16 (InverseBounds::lds16): two tile rows
-// share a dword, which halves the tile (25 KB instead of 50 KB: five workgroups per CU instead of three).
-template <int NS, bool EDGE, bool EXACT, typename MidT, bool LDS16>
-__global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restrict__ mid, uint8_t* __restrict__ rgb,
-                                                           ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
+struct InvXy {
+    const void* mid;             // the band's slot (see InvTm)
+    uint8_t* rgb;
+    ChunkDims d;
+    Coeffs cf;
+    int aligned;
+    BandTiles bt;
+    int L0, rows_l;              // slot rows: low-band rows [L0, L0 + rows_l), then the same rows of the high band
+};
+
+// stage A of both inverse tile kernels: one thread per (extended column, channel) loads its ER rows from the band slot
+// and runs the inverse column lifting in registers.  Rows and columns outside the frame are read through the symmetric
+// extension (reflect_idx), in the interleaved index space, so neither stage needs boundary logic in its arithmetic;
+// rows that only feed never-stored outputs of overhanging tiles are clamped into the slot.
+template <int NS, int ER, bool EDGE, bool EXACT, typename MidT, int PROBE = 0>
+__device__ __forceinline__ void inv_load_lift_column(const InvXy& a, int ch, int par, int px, int t, int gy_s, int (&v)[ER]) {
+    const ChunkDims& d = a.d;
+    const int pw = d.pw, ph = d.ph, hw = pw / 2;
+    const MidT* src = (const MidT*)a.mid + ((size_t)ch * d.pf + t) * ((size_t)2 * a.rows_l * pw) + (size_t)par * hw + (px >> 1);
+    if (PROBE & 1) {
+#pragma unroll
+        for (int k = 0; k < ER; ++k) v[k] = (int)(short)((px + gy_s) * 37 + k * 101 + t);
+    } else if (EDGE) {
+#pragma unroll
+        for (int k = 0; k < ER; ++k) {
+            const int gy = reflect_idx(gy_s + k, ph);
+            const int yl = (gy & 1) * a.rows_l + min(max((gy >> 1) - a.L0, 0), a.rows_l - 1);
+            v[k] = (int)src[(size_t)yl * pw];
+        }
+    } else {
+        // gy_s is even: even rows of the tile are low-band rows gy_s / 2 + m, odd rows the same high-band rows
+        const MidT* lo = src + (size_t)((gy_s >> 1) - a.L0) * pw;
+        const MidT* hi = lo + (size_t)a.rows_l * pw;
+#pragma unroll
+        for (int m = 0; m < ER / 2; ++m) { v[2 * m] = (int)lo[(size_t)m * pw]; v[2 * m + 1] = (int)hi[(size_t)m * pw]; }
+    }
+    lift_regs<ER, NS, EXACT, true>(v, a.cf);
+}
+
+// `as i16` (src/pipeline.rs:608), wrapping i16 colour inverse (src/color.rs:266-273), 8 pixels -> 24 bytes, dword stores
+template <int PROBE = 0>
+__device__ __forceinline__ void store_rgb8(const InvXy& a, bool edge, const int* y, const int* co, const int* cg, int t, int gy, int gxs) {
+    const ChunkDims& d = a.d;
+    uint8_t out[24];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const short yv = (short)y[kk], c_o = (short)co[kk], c_g = (short)cg[kk];
+        const short tt = (short)(yv - (short)(c_g >> 1));
+        const short g = (short)(c_g + tt);
+        const short b = (short)(tt - (short)(c_o >> 1));
+        const short rr = (short)(c_o + b);
+        out[3 * kk] = (uint8_t)min(max((int)rr, 0), 255);
+        out[3 * kk + 1] = (uint8_t)min(max((int)g, 0), 255);
+        out[3 * kk + 2] = (uint8_t)min(max((int)b, 0), 255);
+    }
+    uint8_t* p = a.rgb + (((size_t)t * d.h + gy) * d.w + gxs) * 3;
+    if (PROBE & 2) {
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc ^= ((uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) | ((uint32_t)out[4 * i + 3] << 24)) + (uint32_t)i;
+        if (acc == 0x5EEDF00Du) *(uint32_t*)p = acc;
+    } else if (a.aligned && (!edge || gxs + 8 <= (int)d.w)) {
+        uint32_t* p4 = (uint32_t*)p;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            p4[i] = (uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) |
+                    ((uint32_t)out[4 * i + 3] << 24);
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            if (gxs + kk < (int)d.w) { p[3 * kk] = out[3 * kk]; p[3 * kk + 1] = out[3 * kk + 1]; p[3 * kk + 2] = out[3 * kk + 2]; }
+    }
+}
+
+// Recompute variant with the packed tile: the host proved that every value after the inverse column lifting fits i16
+// (InverseBounds::lds16): two tile rows share a dword, which halves the tile (26 KB: the 32-wave limit, not LDS, then
+// bounds the workgroups per CU).  A stage-B thread lifts its 8 pixels plus NS halo samples on each side.
+template <int NS, bool EDGE, bool EXACT, typename MidT>
+__device__ __forceinline__ void inv_xy_tile_packed(const InvXy& a, int bx, int by, int t, int* lds) {
     constexpr int H = NS;
     constexpr int ER = I_TH + 2 * H;        // rows incl. halo
     constexpr int EC = I_TW + 2 * H;        // columns incl. halo (104 / 100)
     constexpr int ECh = EC / 2;
-    constexpr int LR = LDS16 ? ER / 2 : ER; // LDS rows per channel
+    constexpr int LR = ER / 2;              // LDS rows per channel (two tile rows per dword)
     constexpr int NL = I_SEG + 2 * H;       // samples lifted per segment
-    __shared__ __attribute__((aligned(16))) int lds[3 * LR * I_LW];
+    const ChunkDims& d = a.d;
     const int tid = threadIdx.x;
-    // interior launch: a rectangle of tiles whose halo lies inside the frame (no mirroring, no clamping, no bounds
-    // tests); border launch: one linear sequence over the four strips around it
-    int bx, by, t;
-    if (!tile_of_block<EDGE>(tm, d.f, bx, by, t)) return;
     const int gx0 = bx * I_TW, gy0 = by * I_TH;
-    const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
+    const int pw = d.pw;
     const int gpx0 = (gx0 - H) / 2;  // first column pair of the extended tile (may be negative)
 
-    // stage A: one thread per (extended column, channel): inverse column lifting in registers.  Rows and
-    // columns outside the frame are read through the symmetric extension (reflect_idx), in the interleaved
-    // index space, so neither stage needs boundary logic in its arithmetic.
     if (tid < 3 * EC) {
         const int ch = tid / EC, xq = tid % EC;
         const int par = xq / ECh, j = xq % ECh;
         const int px = EDGE ? reflect_idx(2 * (gpx0 + j) + par, pw) : 2 * (gpx0 + j) + par;   // parity is preserved
-        {
-            int v[ER];
-            const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + (px >> 1);
-            const int gy_s = gy0 - H;
-            if (EDGE) {
+        int v[ER];
+        inv_load_lift_column<NS, ER, EDGE, EXACT, MidT>(a, ch, par, px, t, gy0 - H, v);
+        int* L = lds + (ch * LR) * I_LW + par * I_HO + j;
 #pragma unroll
-                for (int k = 0; k < ER; ++k) {
-                    const int gy = reflect_idx(gy_s + k, ph);
-                    const int yy = (gy & 1) * hh + (gy >> 1);
-                    v[k] = (int)src[(size_t)yy * pw];
-                }
-            } else {
-                // gy_s is even: even rows of the tile are low-band rows gy_s / 2 + m, odd rows high-band rows hh + gy_s / 2 + m
-                const MidT* lo = src + (size_t)(gy_s >> 1) * pw;
-                const MidT* hi = lo + (size_t)hh * pw;
-#pragma unroll
-                for (int m = 0; m < ER / 2; ++m) { v[2 * m] = (int)lo[(size_t)m * pw]; v[2 * m + 1] = (int)hi[(size_t)m * pw]; }
-            }
-            lift_regs<ER, NS, EXACT, true>(v, cf);
-            int* L = lds + (ch * LR) * I_LW + par * I_HO + j;
-            if (LDS16) {
-#pragma unroll
-                for (int m = 0; m < ER / 2; ++m) L[m * I_LW] = (v[2 * m] & 0xFFFF) | (v[2 * m + 1] << 16);
-            } else {
-#pragma unroll
-                for (int k = 0; k < ER; ++k) L[k * I_LW] = v[k];
-            }
-        }
+        for (int m = 0; m < ER / 2; ++m) L[m * I_LW] = (v[2 * m] & 0xFFFF) | (v[2 * m + 1] << 16);
     }
     __syncthreads();
 
     // stage B: one thread per (interior row, 8-pixel segment): inverse row lifting + colour
-    {
+    if (tid < I_TH * I_NSEG) {
         const int r = tid / I_NSEG, s = tid % I_NSEG;  // 384 = 32 * 12
         const int gy = gy0 + r;
         const int gxs = gx0 + s * I_SEG;               // first interior pixel of the segment
@@ -654,63 +814,39 @@ __global__ __launch_bounds__(I_THREADS) void inv_xy_kernel(const MidT* __restric
             // sample k of the segment is extended-tile column s*8 + k: even k in the low half at dword s*4 + k/2,
             // odd k in the high half at I_HO + s*4 + k/2
             const int k = r + H;
-            const int lrow = LDS16 ? (k >> 1) : k;
-            const bool upper = LDS16 && (k & 1);
+            const int lrow = k >> 1;
+            const bool upper = k & 1;
             auto fetch = [&](int ch, int (&dst)[NL]) {
                 const int* Lc = lds + (ch * LR + lrow) * I_LW + s * 4;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const int4 a = *(const int4*)(Lc + half * I_HO);
-                    const int4 b = *(const int4*)(Lc + half * I_HO + 4);
-                    const int w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    const int4 va = *(const int4*)(Lc + half * I_HO);
+                    const int4 vb = *(const int4*)(Lc + half * I_HO + 4);
+                    const int w8[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
                     for (int q = 0; q < NL / 2; ++q) {
                         const int w = w8[q];
-                        dst[2 * q + half] = LDS16 ? (upper ? (w >> 16) : (int)(short)w) : w;
+                        dst[2 * q + half] = upper ? (w >> 16) : (int)(short)w;
                     }
                 }
             };
             fetch(0, y); fetch(1, co); fetch(2, cg);
-            lift_regs<NL, NS, EXACT, true>(y, cf);
-            lift_regs<NL, NS, EXACT, true>(co, cf);
-            lift_regs<NL, NS, EXACT, true>(cg, cf);
-            uint8_t out[I_SEG * 3];
-#pragma unroll
-            for (int kk = 0; kk < I_SEG; ++kk) {
-                // `as i16` (src/pipeline.rs:608) then wrapping i16 arithmetic (src/color.rs:266-273)
-                const short yv = (short)y[H + kk], c_o = (short)co[H + kk], c_g = (short)cg[H + kk];
-                const short tt = (short)(yv - (short)(c_g >> 1));
-                const short g = (short)(c_g + tt);
-                const short b = (short)(tt - (short)(c_o >> 1));
-                const short rr = (short)(c_o + b);
-                out[3 * kk] = (uint8_t)min(max((int)rr, 0), 255);
-                out[3 * kk + 1] = (uint8_t)min(max((int)g, 0), 255);
-                out[3 * kk + 2] = (uint8_t)min(max((int)b, 0), 255);
-            }
-            uint8_t* p = rgb + (((size_t)t * d.h + gy) * d.w + gxs) * 3;
-            if (aligned && (!EDGE || gxs + I_SEG <= (int)d.w)) {
-                uint32_t* p4 = (uint32_t*)p;
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    p4[i] = (uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) |
-                            ((uint32_t)out[4 * i + 3] << 24);
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < I_SEG; ++kk)
-                    if (gxs + kk < (int)d.w) { p[3 * kk] = out[3 * kk]; p[3 * kk + 1] = out[3 * kk + 1]; p[3 * kk + 2] = out[3 * kk + 2]; }
-            }
+            lift_regs<NL, NS, EXACT, true>(y, a.cf);
+            lift_regs<NL, NS, EXACT, true>(co, a.cf);
+            lift_regs<NL, NS, EXACT, true>(cg, a.cf);
+            store_rgb8(a, EDGE, y + H, co + H, cg + H, t, gy, gxs);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4x: the same inverse tile with LANE-EXCHANGE row lifting.  In inv_xy_kernel a stage-B thread lifts its 8 pixels plus
-// NS halo samples on each side (16 samples to keep 8) because it cannot see its neighbours' intermediate values.  Here
+// K4x: the same inverse tile with LANE-EXCHANGE row lifting.  In the recompute variant a stage-B thread lifts its 8 pixels
+// plus NS halo samples on each side (16 samples to keep 8) because it cannot see its neighbours' intermediate values.  Here
 // the 16 lanes of a DPP row hold one tile row -- a left halo segment, twelve 8-pixel segments, a right halo segment --
 // and every lifting step fetches the one neighbour sample it needs with a row_shr / row_shl DPP move: a lane lifts exactly
 // its own 8 samples.  An output depends on inputs at most NS samples away and the halo lanes hold NS true samples next to
 // the tile (their far halves are never-read garbage), so lanes 1..12 end up with the same integers as the global pass.
-// Used whenever the packed-i16 tile of inv_xy_kernel<..., LDS16 = true> is not provably safe (e.g. q = 80).
+// Used whenever the packed-i16 tile is not provably safe (e.g. q = 80).
 // ------------------------------------------------------------------------------------------------
 constexpr int X_TH = 32, X_THREADS = X_TH * 16;   // stage B: X_TH rows x 16 lanes
 constexpr int X_HO = 56, X_LW = 112;    // tile row: even samples at columns 2 .. 53 (+2 never-read columns each side), odd at 56 + ...
@@ -734,95 +870,77 @@ __device__ __forceinline__ void lift_seg8_dpp(int (&v)[8], const Coeffs& cf) {
     }
 }
 
-template <int NS, bool EDGE, bool EXACT, typename MidT>
-__global__ __launch_bounds__(X_THREADS) void inv_xy_dpp_kernel(const MidT* __restrict__ mid, uint8_t* __restrict__ rgb,
-                                                               ChunkDims d, Coeffs cf, int aligned, TileMap tm) {
+template <int NS, bool EDGE, bool EXACT, typename MidT, int PROBE = 0>
+__device__ __forceinline__ void inv_xy_tile_dpp(const InvXy& a, int bx, int by, int t, int* lds) {
     constexpr int H = NS;
     constexpr int ER = X_TH + 2 * H;
     constexpr int EC = I_TW + 2 * H;
     constexpr int ECh = EC / 2;
-    __shared__ __attribute__((aligned(16))) int lds[3 * ER * X_LW];
+    const ChunkDims& d = a.d;
     const int tid = threadIdx.x;
-    int bx, by, t;
-    if (!tile_of_block<EDGE>(tm, d.f, bx, by, t)) return;
     const int gx0 = bx * I_TW, gy0 = by * X_TH;
-    const int pw = d.pw, ph = d.ph, hw = pw / 2, hh = ph / 2;
+    const int pw = d.pw;
     const int gpx0 = (gx0 - H) / 2;
 
-    // stage A: as in inv_xy_kernel; extended column e = 2 j + par goes to tile column par * X_HO + j + (4 - H) / 2 + ...
-    // (the H halo samples of a side end right at the first / last real segment: sample e sits at even/odd column (e + 4 - H) / 2 + 2)
+    // stage A: extended column e = 2 j + par goes to tile column par * X_HO + (8 - H) / 2 + j (the H halo samples of a
+    // side end right at the first / last real segment: the row starts 8 samples left of the tile)
     if (tid < 3 * EC) {
         const int ch = tid / EC, xq = tid % EC;
         const int par = xq / ECh, j = xq % ECh;
         const int px = EDGE ? reflect_idx(2 * (gpx0 + j) + par, pw) : 2 * (gpx0 + j) + par;
         int v[ER];
-        const MidT* src = mid + ((size_t)ch * d.pf + t) * ph * pw + (size_t)par * hw + (px >> 1);
-        const int gy_s = gy0 - H;
-        if (EDGE) {
-#pragma unroll
-            for (int k = 0; k < ER; ++k) {
-                const int gy = reflect_idx(gy_s + k, ph);
-                const int yy = (gy & 1) * hh + (gy >> 1);
-                v[k] = (int)src[(size_t)yy * pw];
-            }
-        } else {
-            const MidT* lo = src + (size_t)(gy_s >> 1) * pw;
-            const MidT* hi = lo + (size_t)hh * pw;
-#pragma unroll
-            for (int m = 0; m < ER / 2; ++m) { v[2 * m] = (int)lo[(size_t)m * pw]; v[2 * m + 1] = (int)hi[(size_t)m * pw]; }
-        }
-        lift_regs<ER, NS, EXACT, true>(v, cf);
-        // pair index of the sample inside the row that starts 8 samples left of the tile: (8 - H) / 2 + j
+        inv_load_lift_column<NS, ER, EDGE, EXACT, MidT, PROBE>(a, ch, par, px, t, gy0 - H, v);
         int* L = lds + (ch * ER) * X_LW + par * X_HO + (8 - H) / 2 + j;
 #pragma unroll
         for (int k = 0; k < ER; ++k) L[k * X_LW] = v[k];
     }
     __syncthreads();
 
-    // stage B: lane s of a 16-lane row holds segment s - 1 (8 samples = 4 even + 4 odd: one ds_read_b128 per half)
+    // stage B: lane s of a 16-lane row holds segment s - 1 (8 samples = 4 even + 4 odd: one ds_read_b128 per half).
+    // Which tile rows share a wave matters: a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
+    // 28-31} (and the same + 32), so lanes of two DPP rows meet in one group.  With the two rows 4 tile rows apart their
+    // bases differ by 4 * 112 = 7 * 64 dwords, the same bank phase, and each group covers 64 different banks (consecutive
+    // rows, 112 = 48 mod 64 apart, were a 2-way conflict on every read: 0.40 of all LDS cycles, scripts/lds_bank_model.py).
     {
-        const int r = tid >> 4, s = tid & 15;
+        const int s = tid & 15, q = (tid >> 4) & 3, pr = 2 * (tid >> 6) + (q >> 1);
+        const int r = 8 * (pr >> 2) + (pr & 3) + 4 * (q & 1);
         const int gy = gy0 + r;
         const int gxs = gx0 + (s - 1) * 8;
         int y[8], co[8], cg[8];
         auto fetch = [&](int ch, int (&dst)[8]) {
             const int* Lc = lds + (ch * ER + r + H) * X_LW + s * 4;
-            const int4 a = s < 14 ? *(const int4*)Lc : make_int4(0, 0, 0, 0);
-            const int4 b = s < 14 ? *(const int4*)(Lc + X_HO) : make_int4(0, 0, 0, 0);
-            dst[0] = a.x; dst[2] = a.y; dst[4] = a.z; dst[6] = a.w;
-            dst[1] = b.x; dst[3] = b.y; dst[5] = b.z; dst[7] = b.w;
+            const int4 va = s < 14 ? *(const int4*)Lc : make_int4(0, 0, 0, 0);
+            const int4 vb = s < 14 ? *(const int4*)(Lc + X_HO) : make_int4(0, 0, 0, 0);
+            dst[0] = va.x; dst[2] = va.y; dst[4] = va.z; dst[6] = va.w;
+            dst[1] = vb.x; dst[3] = vb.y; dst[5] = vb.z; dst[7] = vb.w;
         };
         fetch(0, y); fetch(1, co); fetch(2, cg);
-        lift_seg8_dpp<NS, EXACT, true>(y, cf);
-        lift_seg8_dpp<NS, EXACT, true>(co, cf);
-        lift_seg8_dpp<NS, EXACT, true>(cg, cf);
-        if (s >= 1 && s <= 12 && (!EDGE || (gy < (int)d.h && gxs < (int)d.w))) {
-            uint8_t out[24];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                // `as i16` (src/pipeline.rs:608) then wrapping i16 arithmetic (src/color.rs:266-273)
-                const short yv = (short)y[kk], c_o = (short)co[kk], c_g = (short)cg[kk];
-                const short tt = (short)(yv - (short)(c_g >> 1));
-                const short g = (short)(c_g + tt);
-                const short b = (short)(tt - (short)(c_o >> 1));
-                const short rr = (short)(c_o + b);
-                out[3 * kk] = (uint8_t)min(max((int)rr, 0), 255);
-                out[3 * kk + 1] = (uint8_t)min(max((int)g, 0), 255);
-                out[3 * kk + 2] = (uint8_t)min(max((int)b, 0), 255);
-            }
-            uint8_t* p = rgb + (((size_t)t * d.h + gy) * d.w + gxs) * 3;
-            if (aligned && (!EDGE || gxs + 8 <= (int)d.w)) {
-                uint32_t* p4 = (uint32_t*)p;
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    p4[i] = (uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) |
-                            ((uint32_t)out[4 * i + 3] << 24);
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-                    if (gxs + kk < (int)d.w) { p[3 * kk] = out[3 * kk]; p[3 * kk + 1] = out[3 * kk + 1]; p[3 * kk + 2] = out[3 * kk + 2]; }
-            }
-        }
+        lift_seg8_dpp<NS, EXACT, true>(y, a.cf);
+        lift_seg8_dpp<NS, EXACT, true>(co, a.cf);
+        lift_seg8_dpp<NS, EXACT, true>(cg, a.cf);
+        if (s >= 1 && s <= 12 && (!EDGE || (gy < (int)d.h && gxs < (int)d.w))) store_rgb8<PROBE>(a, EDGE, y, co, cg, t, gy, gxs);
+    }
+}
+
+// the inverse launch: temporal role of this band in blocks [0, n_t), tile role of the previous band behind them.
+// PACKED = the packed-i16 recompute tile (384 threads); otherwise the lane-exchange tile (512 threads).
+template <bool PACKED> struct InvTileShape { static constexpr int kThreads = PACKED ? I_THREADS : X_THREADS;
+                                             static constexpr int kLdsInts = PACKED ? 3 * ((I_TH + 8) / 2) * I_LW : 3 * (X_TH + 8) * X_LW; };
+
+template <int NS, bool EXACT, typename MidT, bool PACKED, int PROBE = 0>
+__global__ __launch_bounds__(InvTileShape<PACKED>::kThreads) void inv_band_kernel(InvXy xa, InvTm ta, unsigned n_t) {
+    __shared__ __attribute__((aligned(16))) int lds[InvTileShape<PACKED>::kLdsInts];
+    const unsigned b = blockIdx.x;
+    if (b < n_t) { inv_t_role<NS, EXACT, MidT, InvTileShape<PACKED>::kThreads, PROBE>(ta, b, lds); return; }
+    int bx, by, t;
+    bool edge;
+    if (!band_tile_of_block(xa.bt, xa.d.f, b - n_t, gridDim.x - n_t, bx, by, t, edge)) return;
+    if (PACKED) {
+        if (edge) inv_xy_tile_packed<NS, true, EXACT, MidT>(xa, bx, by, t, lds);
+        else inv_xy_tile_packed<NS, false, EXACT, MidT>(xa, bx, by, t, lds);
+    } else {
+        if (edge && !(PROBE & 1)) inv_xy_tile_dpp<NS, true, EXACT, MidT, PROBE>(xa, bx, by, t, lds);
+        else inv_xy_tile_dpp<NS, false, EXACT, MidT, PROBE>(xa, bx, by, t, lds);
     }
 }
 
@@ -1042,106 +1160,263 @@ static bool set_dyn_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
-// Tiles strictly inside the frame (no clamping, no mirroring) run the EDGE=false instance, launched as
-// one interior rectangle of tiles; the four border strips run EDGE=true.
-bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
-                              int32_t* d_mid, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
-    if (step < 1 || step > 64) return false;
+// Tuning, settable by the test hook alice_codec_test_set_tuning and, for developer runs, by the environment at first
+// use: ALICE_BAND_KB = target size of a band slot in KiB (0 = never cut a chunk into bands), ALICE_T_BLOCKS = cap on the
+// temporal role's workgroups per launch (0 = one per unit), ALICE_NO_FUSE = 1 gives every role a launch of its own.
+static long env_long(const char* name, long dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atol(v) : dflt;
+}
+struct TransformTuning { long band_kb, t_blocks, no_fuse; };
+static TransformTuning& tuning() {
+    static TransformTuning t{env_long("ALICE_BAND_KB", 64 * 1024), env_long("ALICE_T_BLOCKS", 512), env_long("ALICE_NO_FUSE", 0)};
+    return t;
+}
+void set_transform_tuning(long band_kb, long t_blocks, long no_fuse) {
+    TransformTuning& t = tuning();
+    if (band_kb >= 0) t.band_kb = band_kb;
+    if (t_blocks >= 0) t.t_blocks = t_blocks;
+    if (no_fuse >= 0) t.no_fuse = no_fuse;
+}
+// alice_codec_test_transform_ms(probe = 1): the CDF 9/7, step > 1, i16 lane-exchange instances run their VALU-floor twins
+static thread_local int tl_valu_probe = 0;
+void set_transform_probe(int mode) { tl_valu_probe = mode; }
+
+bool transform_tiles_eligible(const ChunkDims& d) {
     if ((unsigned long long)d.pw * d.ph > (1ull << 30)) return false;   // 32-bit byte offsets inside one frame
     if (d.pw < 6 || d.ph < 6) return false;                             // reflect_idx: one reflection must cover the halo
-    if ((unsigned long long)((d.pw + F_TW - 1) / F_TW) * ((d.ph + F_TH - 1) / F_TH) * d.pf > 0x7FFFFFF0ull) return false;
-    const LiftSteps ls = lift_steps(wavelet);
-    const Coeffs cf = to_coeffs(ls);
-    int16_t* mid = (int16_t*)d_mid;
-    const unsigned nx = (d.pw + F_TW - 1) / F_TW, ny = (d.ph + F_TH - 1) / F_TH;
-    const int aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
-    // a tile is interior when its loaded range [gx0-4, gx0+128+4) x [gy0-H, gy0+40+H) lies inside w x h
-    auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * F_TW + F_TW + 4) <= d.w; };
-    auto interior_y = [&](unsigned by) { return by >= 1 && (by * F_TH + F_TH + 4) <= d.h; };
-    unsigned ix0 = 1, ix1 = 1, iy0 = 1, iy1 = 1;
-    while (ix1 < nx && interior_x(ix1)) ++ix1;
-    while (iy1 < ny && interior_y(iy1)) ++iy1;
-    const bool has_interior = ix1 > ix0 && iy1 > iy0;
-    const size_t lds4 = (size_t)3 * (F_TH + 8) * F_LP * sizeof(int), lds2 = (size_t)3 * (F_TH + 4) * F_LP * sizeof(int);
-    dim3 block(F_THREADS);
-    TileMap tm{(int)nx, (int)ny, 0, 0, 0, 0};
-    if (has_interior) { tm.ix0 = (int)ix0; tm.ix1 = (int)ix1; tm.iy0 = (int)iy0; tm.iy1 = (int)iy1; }
-    else { tm.iy0 = (int)ny; tm.iy1 = (int)ny; }  // everything is "top strip"
-    const unsigned n_interior_x = has_interior ? ix1 - ix0 : 0, n_interior_y = has_interior ? iy1 - iy0 : 0;
-    const unsigned n_edge = nx * ny - n_interior_x * n_interior_y;
-    if (ls.n == 4) {
-        static const bool ok = set_dyn_lds(fwd_xy_kernel<4, true>, lds4) && set_dyn_lds(fwd_xy_kernel<4, false>, lds4);
-        (void)ok;
-        if (has_interior) hipLaunchKernelGGL((fwd_xy_kernel<4, false>), dim3(xcd_grid((unsigned long long)n_interior_x * n_interior_y * d.pf)), block, lds4, st, d_rgb, mid, d, cf, aligned, tm);
-        if (n_edge) hipLaunchKernelGGL((fwd_xy_kernel<4, true>), dim3(xcd_grid((unsigned long long)n_edge * d.pf)), block, lds4, st, d_rgb, mid, d, cf, aligned, tm);
-    } else {
-        static const bool ok = set_dyn_lds(fwd_xy_kernel<2, true>, lds2) && set_dyn_lds(fwd_xy_kernel<2, false>, lds2);
-        (void)ok;
-        if (has_interior) hipLaunchKernelGGL((fwd_xy_kernel<2, false>), dim3(xcd_grid((unsigned long long)n_interior_x * n_interior_y * d.pf)), block, lds2, st, d_rgb, mid, d, cf, aligned, tm);
-        if (n_edge) hipLaunchKernelGGL((fwd_xy_kernel<2, true>), dim3(xcd_grid((unsigned long long)n_edge * d.pf)), block, lds2, st, d_rgb, mid, d, cf, aligned, tm);
-    }
-    const size_t plane = (size_t)d.pw * d.ph;
-    const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
-    dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
-#define ALICE_FWD_T(NS_, S1_) hipLaunchKernelGGL((fwd_t_kernel<NS_, S1_, true>), gt, dim3(256), 0, st, mid, d_sym, d_hist, d, cf, step, magic)
-    if (ls.n == 4) { if (step == 1) ALICE_FWD_T(4, true); else ALICE_FWD_T(4, false); }
-    else { if (step == 1) ALICE_FWD_T(2, true); else ALICE_FWD_T(2, false); }
-#undef ALICE_FWD_T
+    if ((unsigned long long)((d.pw + I_TW - 1) / I_TW) * ((d.ph + I_TH - 1) / I_TH) * d.pf > 0x7FFFFFF0ull) return false;
     return true;
 }
 
-template <int NS, bool EXACT, typename MidT, bool LDS16>
-static void inv_launch(const uint8_t* sym, MidT* mid, uint8_t* rgb, const ChunkDims& d, Coeffs cf, const int32_t step[3],
-                       hipStream_t st) {
-    const size_t plane = (size_t)d.pw * d.ph;
-    dim3 gt((unsigned)((plane / 4 + 255) / 256), 3);
-    hipLaunchKernelGGL((inv_t_kernel<NS, EXACT, MidT>), gt, dim3(256), 0, st, sym, mid, d, cf, step[0], step[1], step[2]);
-    const unsigned th = LDS16 ? (unsigned)I_TH : (unsigned)X_TH;   // tile height of the kernel that will run
-    const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + th - 1) / th;
-    const int aligned = (d.w % 4 == 0) && ((((uintptr_t)rgb) & 3u) == 0u);
-    // a tile is interior when the range it reads, [gx0 - 4, gx0 + 96 + 4) x [gy0 - 4, gy0 + th + 4), lies inside w x h
-    // (then inside the padded frame too, and every pixel it writes exists)
-    auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * I_TW + I_TW + 4) <= d.w; };
-    auto interior_y = [&](unsigned by) { return by >= 1 && (by * th + th + 4) <= d.h; };
+// Band plan of a chunk for tiles of tile_h rows: bands of `tpb` tile rows (the last one takes what is left).  Cut only
+// when the padded width is a multiple of 4 (see the header comment) and there are at least two bands' worth of rows.
+BandPlan plan_bands(const ChunkDims& d, int tile_h, size_t bytes_per_sample, int halo_rows) {
+    BandPlan p{};
+    p.tile_h = tile_h;
+    p.tiles_y = (int)((d.ph + tile_h - 1) / tile_h);
+    const size_t row_bytes = (size_t)d.pw * d.pf * 3 * bytes_per_sample;     // one padded row of all frames and channels
+    long tpb = p.tiles_y;
+    const long target = tuning().band_kb;
+    if (target > 0 && d.pw % 4 == 0) {
+        tpb = (long)(((size_t)target << 10) / (row_bytes * (size_t)tile_h));
+        if (tpb < 1) tpb = 1;
+        if (tpb * 2 > p.tiles_y) tpb = p.tiles_y;                            // fewer than two bands: do not cut
+    }
+    p.tpb = (int)tpb;
+    p.n_bands = (p.tiles_y + p.tpb - 1) / p.tpb;
+    // rows a slot holds: the band's own rows (+ the halo rows of the inverse band on either side), or the whole frame
+    const size_t slot_rows = p.n_bands > 1 ? std::min<size_t>((size_t)p.tpb * tile_h, d.ph) + (size_t)2 * halo_rows : d.ph;
+    p.slot_bytes = ((slot_rows * row_bytes + 255) / 256) * 256 + 256;
+    p.slots = p.n_bands > 1 ? 2 : 1;
+    return p;
+}
+
+size_t forward_scratch_bytes(const ChunkDims& d) {
+    const BandPlan p = plan_bands(d, F_TH, sizeof(int16_t), 0);
+    return p.slot_bytes * p.slots;
+}
+size_t inverse_scratch_bytes(const ChunkDims& d, bool mid16) {
+    const BandPlan p = plan_bands(d, I_TH, mid16 ? sizeof(int16_t) : sizeof(int32_t), 4);
+    return p.slot_bytes * p.slots;
+}
+
+static BandT make_band_t(const ChunkDims& d, uint32_t band_px, uint32_t seg_px, uint32_t lo_base, uint32_t hi_base, int threads) {
+    BandT b{};
+    b.pf = (uint32_t)d.pf; b.band_px = band_px; b.seg_px = seg_px; b.lo_base = lo_base; b.hi_base = hi_base;
+    b.plane = d.pw * d.ph;
+    b.units_per_ch = (band_px + (uint32_t)threads * 4u - 1u) / ((uint32_t)threads * 4u);
+    const long cap = tuning().t_blocks;
+    b.n_blocks = 3u * b.units_per_ch;
+    if (cap > 0 && b.n_blocks > (uint32_t)cap) b.n_blocks = (uint32_t)cap;
+    return b;
+}
+
+static inline unsigned round_up8(unsigned v) { return (v + 7u) & ~7u; }
+
+// ---- forward ----
+
+template <int NS, bool STEP1, int PROBE = 0>
+static void fwd_band_launch(const FwdXy* xa, const FwdTm* ta, hipStream_t st) {
+    static const bool ok = set_dyn_lds(fwd_band_kernel<NS, STEP1, PROBE>, (size_t)3 * (F_TH + 2 * NS) * F_LP * sizeof(int));
+    (void)ok;
+    const size_t lds = (size_t)3 * (F_TH + 2 * NS) * F_LP * sizeof(int);   // >= the 32 KB of histogram replicas of the temporal role
+    static_assert(3 * (F_TH + 4) * F_LP * sizeof(int) >= kHistWords * sizeof(uint32_t), "tile LDS must hold the histogram replicas");
+    FwdXy x0{}; FwdTm t0{};
+    const unsigned n_t = ta ? round_up8(ta->b.n_blocks) : 0u;
+    const unsigned long long tiles = xa ? (unsigned long long)xa->bt.nx * xa->bt.nby * xa->d.pf : 0ull;
+    const unsigned n_xy = xcd_grid(tiles);
+    if (n_t + n_xy == 0) return;
+    hipLaunchKernelGGL((fwd_band_kernel<NS, STEP1, PROBE>), dim3(n_t + n_xy), dim3(F_THREADS), lds, st, xa ? *xa : x0, ta ? *ta : t0, n_t);
+}
+
+void ForwardPipe::launch(const FwdXy* xa, const FwdTm* ta, hipStream_t st) {
+    if (tuning().no_fuse && xa && ta) { launch(nullptr, ta, st); launch(xa, nullptr, st); return; }
+    if (ns_ == 4 && !step1_ && tl_valu_probe) {
+        if (tl_valu_probe == 1) fwd_band_launch<4, false, 3>(xa, ta, st);        // loads and stores replaced
+        else if (tl_valu_probe == 2) fwd_band_launch<4, false, 1>(xa, ta, st);   // loads replaced
+        else fwd_band_launch<4, false, 2>(xa, ta, st);                           // stores replaced
+        return;
+    }
+    if (ns_ == 4) { if (step1_) fwd_band_launch<4, true>(xa, ta, st); else fwd_band_launch<4, false>(xa, ta, st); }
+    else { if (step1_) fwd_band_launch<2, true>(xa, ta, st); else fwd_band_launch<2, false>(xa, ta, st); }
+}
+
+ForwardPipe::ForwardPipe() : pending_(new FwdTm()) {}
+ForwardPipe::~ForwardPipe() { delete pending_; }
+
+void ForwardPipe::flush(hipStream_t st) {
+    if (!has_pending_) return;
+    launch(nullptr, pending_, st);
+    has_pending_ = false;
+}
+
+bool ForwardPipe::enqueue(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step, void* scratch,
+                          uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
+    if (step < 1 || step > 64) return false;
+    if (!transform_tiles_eligible(d)) return false;
+    const LiftSteps ls = lift_steps(wavelet);
+    const BandPlan bp = plan_bands(d, F_TH, sizeof(int16_t), 0);
+    // the fused launch runs both roles with one set of template arguments, and the two-slot ring assumes one slot size
+    const bool same = has_pending_ && ns_ == ls.n && step1_ == (step == 1) && scratch == scratch_ && bp.slot_bytes == slot_bytes_ && bp.slots == 2;
+    if (!same) flush(st);
+    ns_ = ls.n; step1_ = step == 1; scratch_ = scratch; slot_bytes_ = bp.slot_bytes;
+    const Coeffs cf = to_coeffs(ls);
+    const unsigned nx = (unsigned)((d.pw + F_TW - 1) / F_TW), ny = (unsigned)bp.tiles_y;
+    // a tile is interior when its loaded range [gx0-4, gx0+128+4) x [gy0-H, gy0+40+H) lies inside w x h
+    auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * F_TW + F_TW + 4) <= d.w; };
+    auto interior_y = [&](unsigned by) { return by >= 1 && (by * F_TH + F_TH + 4) <= d.h; };
     unsigned ix1 = 1, iy1 = 1;
     while (ix1 < nx && interior_x(ix1)) ++ix1;
     while (iy1 < ny && interior_y(iy1)) ++iy1;
-    const bool has_interior = ix1 > 1 && iy1 > 1;
-    TileMap tm{(int)nx, (int)ny, 0, 0, 0, 0};
-    if (has_interior) { tm.ix0 = 1; tm.ix1 = (int)ix1; tm.iy0 = 1; tm.iy1 = (int)iy1; }
-    else { tm.iy0 = (int)ny; tm.iy1 = (int)ny; }  // everything is "top strip"
-    const unsigned long long n_in = has_interior ? (unsigned long long)(ix1 - 1) * (iy1 - 1) : 0ull;
-    const unsigned long long n_edge = (unsigned long long)nx * ny - n_in;
-    // packed-i16 tile provable: inv_xy_kernel (25 KB of LDS, five workgroups per CU); otherwise the lane-exchange kernel
-    if (!LDS16) {
-        if (n_in) hipLaunchKernelGGL((inv_xy_dpp_kernel<NS, false, EXACT, MidT>), dim3(xcd_grid(n_in * d.f)), dim3(X_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
-        if (n_edge) hipLaunchKernelGGL((inv_xy_dpp_kernel<NS, true, EXACT, MidT>), dim3(xcd_grid(n_edge * d.f)), dim3(X_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
+    const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
+    const uint32_t hh = (uint32_t)(d.ph / 2), pw = (uint32_t)d.pw;
+    for (int band = 0; band < bp.n_bands; ++band) {
+        const int by0 = band * bp.tpb, nby = std::min(bp.tpb, bp.tiles_y - by0);
+        const int y0 = by0 * F_TH, rows = (int)std::min<uint64_t>((uint64_t)(by0 + nby) * F_TH, d.ph) - y0;
+        if (bp.slots == 2) slot_ ^= 1; else slot_ = 0;
+        int16_t* mid = (int16_t*)((char*)scratch + (size_t)slot_ * bp.slot_bytes);
+        FwdXy xa{};
+        xa.rgb = d_rgb; xa.mid = mid; xa.d = d; xa.cf = cf;
+        xa.aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
+        xa.bt = BandTiles{(int)nx, by0, nby, 1, (int)ix1, 1, (int)iy1};
+        xa.y0 = y0; xa.rows = rows;
+        launch(&xa, has_pending_ ? pending_ : nullptr, st);
+        FwdTm& ta = *pending_;
+        ta.mid = mid; ta.sym = d_sym; ta.hist = d_hist; ta.cf = cf; ta.hdz = (uint32_t)step / 2u; ta.magic = magic;
+        ta.b = make_band_t(d, (uint32_t)rows * pw, (uint32_t)(rows / 2) * pw, (uint32_t)(y0 / 2) * pw, (hh + (uint32_t)(y0 / 2)) * pw, F_THREADS);
+        has_pending_ = true;
+    }
+    if (bp.slots == 1) flush(st);   // an uncut chunk owns the whole scratch: its temporal pass cannot wait for the next chunk
+    return true;
+}
+
+bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
+                              void* d_scratch, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
+    ForwardPipe p;
+    if (!p.enqueue(d_rgb, d, wavelet, step, d_scratch, d_sym, d_hist, st)) return false;
+    p.flush(st);
+    return true;
+}
+
+// ---- inverse ----
+
+template <int NS, bool EXACT, typename MidT, bool PACKED, int PROBE = 0>
+static void inv_band_launch(const InvXy* xa, const InvTm* ta, hipStream_t st) {
+    InvXy x0{}; InvTm t0{};
+    const unsigned n_t = ta ? round_up8(ta->b.n_blocks) : 0u;
+    const unsigned long long tiles = xa ? (unsigned long long)xa->bt.nx * xa->bt.nby * xa->d.f : 0ull;
+    const unsigned n_xy = xcd_grid(tiles);
+    if (n_t + n_xy == 0) return;
+    hipLaunchKernelGGL((inv_band_kernel<NS, EXACT, MidT, PACKED, PROBE>), dim3(n_t + n_xy), dim3(InvTileShape<PACKED>::kThreads), 0, st,
+                       xa ? *xa : x0, ta ? *ta : t0, n_t);
+}
+
+void InversePipe::launch(const InvXy* xa, const InvTm* ta, hipStream_t st) {
+    if (tuning().no_fuse && xa && ta) { launch(nullptr, ta, st); launch(xa, nullptr, st); return; }
+    // variant: 0 exact (i32), 1 fast i32, 2 fast i16 lane-exchange tile, 3 fast i16 packed tile
+    if (ns_ == 4 && variant_ == 2 && tl_valu_probe) {
+        if (tl_valu_probe == 1) inv_band_launch<4, false, int16_t, false, 3>(xa, ta, st);
+        else if (tl_valu_probe == 2) inv_band_launch<4, false, int16_t, false, 1>(xa, ta, st);
+        else inv_band_launch<4, false, int16_t, false, 2>(xa, ta, st);
         return;
     }
-    if (n_in) hipLaunchKernelGGL((inv_xy_kernel<NS, false, EXACT, MidT, LDS16>), dim3(xcd_grid(n_in * d.f)), dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
-    if (n_edge) hipLaunchKernelGGL((inv_xy_kernel<NS, true, EXACT, MidT, LDS16>), dim3(xcd_grid(n_edge * d.f)), dim3(I_THREADS), 0, st, mid, rgb, d, cf, aligned, tm);
+#define ALICE_INV(NS_) \
+    switch (variant_) { \
+    case 0: inv_band_launch<NS_, true, int32_t, false>(xa, ta, st); break; \
+    case 1: inv_band_launch<NS_, false, int32_t, false>(xa, ta, st); break; \
+    case 2: inv_band_launch<NS_, false, int16_t, false>(xa, ta, st); break; \
+    default: inv_band_launch<NS_, false, int16_t, true>(xa, ta, st); break; \
+    }
+    if (ns_ == 4) { ALICE_INV(4) } else { ALICE_INV(2) }
+#undef ALICE_INV
+}
+
+InversePipe::InversePipe() : pending_(new InvXy()) {}
+InversePipe::~InversePipe() { delete pending_; }
+
+void InversePipe::flush(hipStream_t st) {
+    if (!has_pending_) return;
+    launch(pending_, nullptr, st);
+    has_pending_ = false;
+}
+
+bool InversePipe::enqueue(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3], bool exact, bool mid16,
+                          bool lds16, void* scratch, uint8_t* d_rgb, hipStream_t st) {
+    if (!transform_tiles_eligible(d)) return false;
+    const LiftSteps ls = lift_steps(wavelet);
+    // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too);
+    // lds16: also after the inverse column pass (packed tile)
+    const int variant = exact ? 0 : (mid16 ? (lds16 ? 3 : 2) : 1);
+    const bool m16 = variant >= 2;
+    const BandPlan bp = plan_bands(d, I_TH, m16 ? sizeof(int16_t) : sizeof(int32_t), 4);
+    const bool same = has_pending_ && ns_ == ls.n && variant_ == variant && scratch == scratch_ && bp.slot_bytes == slot_bytes_ && bp.slots == 2;
+    if (!same) flush(st);
+    ns_ = ls.n; variant_ = variant; scratch_ = scratch; slot_bytes_ = bp.slot_bytes;
+    const Coeffs cf = to_coeffs(ls);
+    const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + I_TH - 1) / I_TH;   // tiles over the REAL frame (every pixel written exists)
+    // a tile is interior when the range it reads, [gx0 - 4, gx0 + 96 + 4) x [gy0 - 4, gy0 + 32 + 4), lies inside w x h
+    // (then inside the padded frame too)
+    auto interior_x = [&](unsigned bx) { return bx >= 1 && (bx * I_TW + I_TW + 4) <= d.w; };
+    auto interior_y = [&](unsigned by) { return by >= 1 && (by * I_TH + I_TH + 4) <= d.h; };
+    unsigned ix1 = 1, iy1 = 1;
+    while (ix1 < nx && interior_x(ix1)) ++ix1;
+    while (iy1 < ny && interior_y(iy1)) ++iy1;
+    const int hh = (int)(d.ph / 2);
+    const uint32_t pw = (uint32_t)d.pw;
+    const int n_bands = bp.n_bands > 1 ? ((int)ny + bp.tpb - 1) / bp.tpb : 1;
+    for (int band = 0; band < n_bands; ++band) {
+        const int by0 = n_bands > 1 ? band * bp.tpb : 0, nby = n_bands > 1 ? std::min(bp.tpb, (int)ny - by0) : (int)ny;
+        // slot rows: the band's own rows plus two halo rows of each half on either side, inside the frame
+        int L0 = 0, L1 = hh;
+        if (n_bands > 1) {
+            const int Y0 = by0 * I_TH, Y1 = (int)std::min<uint64_t>((uint64_t)(by0 + nby) * I_TH, d.ph);
+            L0 = std::max(0, Y0 / 2 - 2); L1 = std::min(hh, Y1 / 2 + 2);
+        }
+        const int rows_l = L1 - L0;
+        if (bp.slots == 2) slot_ ^= 1; else slot_ = 0;
+        void* mid = (char*)scratch + (size_t)slot_ * bp.slot_bytes;
+        InvTm ta{};
+        ta.sym = d_sym; ta.mid = mid; ta.cf = cf; ta.step[0] = step[0]; ta.step[1] = step[1]; ta.step[2] = step[2]; ta.nf = d.f;
+        ta.b = make_band_t(d, 2u * (uint32_t)rows_l * pw, (uint32_t)rows_l * pw, (uint32_t)L0 * pw, (uint32_t)(hh + L0) * pw,
+                           variant == 3 ? I_THREADS : X_THREADS);
+        launch(has_pending_ ? pending_ : nullptr, &ta, st);
+        InvXy& xa = *pending_;
+        xa.mid = mid; xa.rgb = d_rgb; xa.d = d; xa.cf = cf;
+        xa.aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
+        xa.bt = BandTiles{(int)nx, by0, nby, 1, (int)ix1, 1, (int)iy1};
+        xa.L0 = L0; xa.rows_l = rows_l;
+        has_pending_ = true;
+    }
+    if (bp.slots == 1) flush(st);
+    return true;
 }
 
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
-                              bool exact, bool mid16, bool lds16, int32_t* d_mid, uint8_t* d_rgb, hipStream_t st) {
-    const LiftSteps ls = lift_steps(wavelet);
-    const Coeffs cf = to_coeffs(ls);
-    if ((unsigned long long)d.pw * d.ph > (1ull << 30)) return false;   // 32-bit byte offsets inside one frame
-    if (d.pw < 6 || d.ph < 6) return false;                             // reflect_idx: one reflection must cover the halo
-    if ((unsigned long long)((d.w + I_TW - 1) / I_TW) * ((d.h + X_TH - 1) / X_TH) * d.f > 0x7FFFFFF0ull) return false;
-    // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too);
-    // lds16: also after the inverse column pass
-    if (ls.n == 4) {
-        if (exact) inv_launch<4, true, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
-        else if (mid16 && lds16) inv_launch<4, false, int16_t, true>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
-        else if (mid16) inv_launch<4, false, int16_t, false>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
-        else inv_launch<4, false, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
-    } else {
-        if (exact) inv_launch<2, true, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
-        else if (mid16 && lds16) inv_launch<2, false, int16_t, true>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
-        else if (mid16) inv_launch<2, false, int16_t, false>(d_sym, (int16_t*)d_mid, d_rgb, d, cf, step, st);
-        else inv_launch<2, false, int32_t, false>(d_sym, d_mid, d_rgb, d, cf, step, st);
-    }
+                              bool exact, bool mid16, bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st) {
+    InversePipe p;
+    if (!p.enqueue(d_sym, d, wavelet, step, exact, mid16, lds16, d_scratch, d_rgb, st)) return false;
+    p.flush(st);
     return true;
 }
 

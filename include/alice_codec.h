@@ -88,13 +88,7 @@ const char *alice_codec_last_error_message(void); /* thread-local, valid until t
 int alice_codec_device_count(void);
 int alice_codec_set_device(int device);           /* device used by this thread's later calls */
 void alice_codec_trim(void);                      /* release cached device memory */
-/* TEST ONLY: the next encodes size their stream regions with this capacity instead of the histogram-derived one
- * (0 = off), so that the suite can drive the overflow-and-retry path.  Never needed by a caller. */
-void alice_codec_test_force_first_cap(uint64_t cap);
-/* TEST ONLY: the last alice_codec_rans_decode / alice_codec_dev_rans_decode of the calling thread: tiles taken by the fast
- * path, tiles taken by the exact loop, the mask of tile-loop branches that ran (kDecPath* in csrc/kernels.h), stream
- * bytes consumed. */
-void alice_codec_test_last_decode_stats(uint32_t out[4]);
+/* (test and measurement hooks live in alice_codec_test.h, which this header does not include) */
 
 /* FrameEncoder::with_wavelet (src/pipeline.rs:356) */
 FrameEncoder *alice_codec_encoder_create_ex(uint8_t quality, uint8_t wavelet_type);
@@ -118,6 +112,20 @@ void alice_codec_data_free64(uint8_t *ptr, uint64_t len);
 int alice_codec_encode_many(const FrameEncoder *encoder, const uint8_t *rgb, uint64_t rgb_len, uint32_t width,
                             uint32_t height, uint32_t frames, uint32_t n_chunks, EncodedChunk **out_chunks);
 int alice_codec_decode_many(const EncodedChunk *const *chunks, uint32_t n_chunks, uint8_t *rgb_out, uint64_t rgb_out_len);
+/* (Both take as many chunks at a time as the device's memory holds and loop over the rest.)
+ *
+ * The same over several GPUs of the node, for hosts that are not Python (the chunk driver of src/pipeline.rs:461-497:
+ * 64-frame chunks are independent bitstreams).  Chunk k runs on devices[k mod n_devices]; the library starts one host
+ * thread with one HIP stream per entry of the list, every device copies its own chunks in and its own results out (its
+ * own PCIe link; nothing is staged on another GPU), and results arrive in chunk order.  A device may be listed more than
+ * once (two host threads sharing it).  Byte-identical to alice_codec_encode_many / decode_many for every device list.
+ * alice_codec_many_devices_plan fills device_of_chunk[n_chunks] with that assignment (no device is touched). */
+int alice_codec_many_devices_plan(uint32_t n_chunks, const int *devices, uint32_t n_devices, int *device_of_chunk);
+int alice_codec_encode_many_devices(const FrameEncoder *encoder, const uint8_t *rgb, uint64_t rgb_len, uint32_t width,
+                                    uint32_t height, uint32_t frames, uint32_t n_chunks, const int *devices,
+                                    uint32_t n_devices, EncodedChunk **out_chunks);
+int alice_codec_decode_many_devices(const EncodedChunk *const *chunks, uint32_t n_chunks, const int *devices,
+                                    uint32_t n_devices, uint8_t *rgb_out, uint64_t rgb_out_len);
 
 /* ---- device-resident batches: n_chunks equal-shaped chunks, inputs and outputs in HBM ---- */
 typedef struct AliceBatch AliceBatch;
@@ -185,6 +193,35 @@ uint8_t *alice_codec_rans_encode(const uint8_t *symbols, uint64_t n, const uint1
 /* RansDecoder::new(bytes).decode_n(n, table) (src/rans.rs:330-381); cum_to_sym is rebuilt from the arrays */
 int alice_codec_rans_decode(const uint8_t *bytes, uint64_t len, const uint16_t cum_freq[256],
                             const uint16_t freq[256], uint64_t n, uint8_t *symbols);
+/* FrequencyTable::from_histogram(&[u32]) for a slice of n_symbols bins, 1 <= n_symbols <= 256 (src/rans.rs:102-150; an
+ * all-zero slice gives FrequencyTable::uniform(n_symbols), :106-109,158-189).  Entries from n_symbols on come back as
+ * (0, 0): those symbols do not exist, and encoding one is an error (the reference indexes out of bounds).  n_symbols = 0:
+ * ALICE_ERR_REFERENCE_DIVERGES (the reference divides by zero). */
+int alice_codec_freq_table_from_histogram_n(const uint32_t *hist, uint32_t n_symbols, uint16_t cum_freq[256], uint16_t freq[256]);
+/* RansEncoder as an object that lives across calls (src/rans.rs:238-309): new / with_capacity, encode(&RansSymbol),
+ * encode_symbols (any number of calls: each continues the state, so s1 then s2 leaves the stream of one call on
+ * s2 || s1), finish (consumes the encoder; buffer to free with alice_codec_data_free64). */
+typedef struct AliceRansEncoder AliceRansEncoder;
+AliceRansEncoder *alice_codec_rans_encoder_new(void);
+void alice_codec_rans_encoder_destroy(AliceRansEncoder *e);
+int alice_codec_rans_encoder_encode(AliceRansEncoder *e, uint16_t cum_freq, uint16_t freq);
+int alice_codec_rans_encoder_encode_symbols(AliceRansEncoder *e, const uint8_t *symbols, uint64_t n,
+                                            const uint16_t cum_freq[256], const uint16_t freq[256]);
+uint32_t alice_codec_rans_encoder_state(const AliceRansEncoder *e);
+uint8_t *alice_codec_rans_encoder_finish(AliceRansEncoder *e, uint64_t *out_len);
+/* RansDecoder as an object (src/rans.rs:321-389): new (copies the input), decode_n (continues from the current state and
+ * position; decode() is decode_n(1)), is_empty. */
+typedef struct AliceRansDecoder AliceRansDecoder;
+AliceRansDecoder *alice_codec_rans_decoder_new(const uint8_t *data, uint64_t len);
+void alice_codec_rans_decoder_destroy(AliceRansDecoder *d);
+int alice_codec_rans_decoder_decode_n(AliceRansDecoder *d, uint64_t n, const uint16_t cum_freq[256], const uint16_t freq[256],
+                                      uint8_t *symbols);
+int alice_codec_rans_decoder_is_empty(const AliceRansDecoder *d);
+uint32_t alice_codec_rans_decoder_state(const AliceRansDecoder *d);
+uint64_t alice_codec_rans_decoder_position(const AliceRansDecoder *d);
+/* quantize_subband / dequantize_subband (src/quant.rs:518-545): a sub-band's coefficients through a Quantizer */
+int alice_codec_quantize_subband(int32_t step, int32_t dead_zone, const int32_t *coeffs, uint64_t n, int32_t *out, uint64_t n_out);
+int alice_codec_dequantize_subband(int32_t step, const int32_t *coeffs, uint64_t n, int32_t *out, uint64_t n_out);
 /* ssim / ms_ssim (src/ssim.rs:63-176): mean SSIM over 8x8 blocks of two single-plane images, and the 3-scale
  * variant.  Bit-identical f64 results (block sums are exact, the mean over blocks is folded in raster order).
  * Returns -1.0 on the reference's Err cases (length mismatch), with alice_codec_last_error() set. */

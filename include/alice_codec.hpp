@@ -75,6 +75,7 @@ public:
     }
     static EncodedChunk from_bytes(const std::vector<uint8_t>& v) { return from_bytes(v.data(), v.size()); }
     const ::EncodedChunk* handle() const { return h_; }
+    static EncodedChunk adopt(::EncodedChunk* h) { return EncodedChunk(h); }   // takes ownership of a handle from the C ABI
 private:
     void reset() { if (h_) alice_codec_chunk_destroy(h_); h_ = nullptr; }
     ::EncodedChunk* h_;
@@ -96,6 +97,7 @@ public:
     EncodedChunk encode(const std::vector<uint8_t>& rgb, uint32_t w, uint32_t h, uint32_t f) const {
         return encode(rgb.data(), rgb.size(), w, h, f);
     }
+    const ::FrameEncoder* handle() const { return h_; }
 private:
     FrameEncoder(uint8_t q, WaveletType w) : h_(alice_codec_encoder_create_ex(q, static_cast<uint8_t>(w))) { if (!h_) detail::raise(); }
     ::FrameEncoder* h_;
@@ -110,6 +112,34 @@ struct FrameDecoder {
         return detail::take(p, n);
     }
 };
+
+// Many equal-shaped chunks in one call (the 64-frame chunk driver, src/pipeline.rs:461-497).  devices empty: the calling
+// thread's device; otherwise chunk k runs on devices[k mod n], one host thread per entry of the list.
+inline std::vector<EncodedChunk> encode_many(const FrameEncoder& enc, const std::vector<uint8_t>& rgb, uint32_t w, uint32_t h, uint32_t f,
+                                             uint32_t n_chunks, const std::vector<int>& devices = {}) {
+    std::vector<::EncodedChunk*> raw(n_chunks, nullptr);
+    static const uint8_t empty = 0;
+    const uint8_t* p = rgb.empty() ? &empty : rgb.data();
+    if (devices.empty()) detail::check(alice_codec_encode_many(enc.handle(), p, rgb.size(), w, h, f, n_chunks, raw.data()));
+    else detail::check(alice_codec_encode_many_devices(enc.handle(), p, rgb.size(), w, h, f, n_chunks, devices.data(),
+                                                       static_cast<uint32_t>(devices.size()), raw.data()));
+    std::vector<EncodedChunk> out;
+    out.reserve(n_chunks);
+    for (auto* c : raw) out.push_back(EncodedChunk::adopt(c));
+    return out;
+}
+inline std::vector<uint8_t> decode_many(const std::vector<EncodedChunk>& chunks, const std::vector<int>& devices = {}) {
+    if (chunks.empty()) return {};
+    std::vector<const ::EncodedChunk*> raw;
+    for (const auto& c : chunks) raw.push_back(c.handle());
+    std::vector<uint8_t> out((size_t)chunks[0].width() * chunks[0].height() * chunks[0].frames() * 3 * chunks.size());
+    static uint8_t sink = 0;
+    uint8_t* p = out.empty() ? &sink : out.data();
+    if (devices.empty()) detail::check(alice_codec_decode_many(raw.data(), static_cast<uint32_t>(raw.size()), p, out.size()));
+    else detail::check(alice_codec_decode_many_devices(raw.data(), static_cast<uint32_t>(raw.size()), devices.data(),
+                                                       static_cast<uint32_t>(devices.size()), p, out.size()));
+    return out;
+}
 
 class Wavelet1D {
 public:
@@ -213,6 +243,14 @@ private:
     ::FastQuantizer* h_;
 };
 
+// quantize_subband / dequantize_subband (src/quant.rs:518-545)
+inline void quantize_subband(const std::vector<int32_t>& coeffs, const Quantizer& q, std::vector<int32_t>& out) {
+    detail::check(alice_codec_quantize_subband(q.step, q.dead_zone, coeffs.data(), coeffs.size(), out.data(), out.size()));
+}
+inline void dequantize_subband(const std::vector<int32_t>& coeffs, const Quantizer& q, std::vector<int32_t>& out) {
+    detail::check(alice_codec_dequantize_subband(q.step, coeffs.data(), coeffs.size(), out.data(), out.size()));
+}
+
 inline void to_symbols(const std::vector<int32_t>& coeffs, std::vector<uint8_t>& symbols) {
     detail::check(alice_codec_to_symbols(coeffs.data(), coeffs.size(), symbols.data(), symbols.size()));
 }
@@ -226,47 +264,78 @@ inline std::array<uint32_t, 256> build_histogram(const std::vector<uint8_t>& sym
     return h;
 }
 
-struct FrequencyTable {  // src/rans.rs:85-219 (256-symbol alphabet)
+struct RansSymbol {  // src/rans.rs:59-72
+    uint16_t cum_freq = 0, freq = 0;
+};
+
+struct FrequencyTable {  // src/rans.rs:85-219; n symbols, 1 <= n <= 256 (entries from n on are (0, 0))
     std::array<uint16_t, 256> cum_freq{}, freq{};
+    size_t n_symbols = 256;
+    static FrequencyTable from_histogram(const std::vector<uint32_t>& hist) {      // any slice length (src/rans.rs:102-104)
+        FrequencyTable t;
+        static const uint32_t empty = 0;
+        detail::check(alice_codec_freq_table_from_histogram_n(hist.empty() ? &empty : hist.data(), static_cast<uint32_t>(hist.size()),
+                                                              t.cum_freq.data(), t.freq.data()));
+        t.n_symbols = hist.size();
+        return t;
+    }
     static FrequencyTable from_histogram(const std::array<uint32_t, 256>& hist) {
         FrequencyTable t;
         detail::check(alice_codec_freq_table_from_histogram(hist.data(), t.cum_freq.data(), t.freq.data()));
         return t;
     }
-    static FrequencyTable uniform() { return from_histogram(std::array<uint32_t, 256>{}); }
-    size_t len() const { return 256; }
+    static FrequencyTable uniform(size_t n = 256) { return from_histogram(std::vector<uint32_t>(n, 0u)); }   // :158-189
+    RansSymbol get_symbol(uint8_t sym) const {                                                               // :194
+        if (sym >= n_symbols) detail::raise(ALICE_ERR_INVALID_DIMENSIONS);   // the reference panics
+        return RansSymbol{cum_freq[sym], freq[sym]};
+    }
+    size_t len() const { return n_symbols; }
+    bool is_empty() const { return n_symbols == 0; }
 };
 
-class RansEncoder {  // src/rans.rs:238-309
+class RansEncoder {  // src/rans.rs:238-309: lives across calls; encode / encode_symbols continue one state
 public:
-    static RansEncoder new_() { return {}; }
-    static RansEncoder with_capacity(size_t) { return {}; }
-    void encode_symbols(const std::vector<uint8_t>& symbols, const FrequencyTable& table) { sym_ = symbols; table_ = table; }
-    std::vector<uint8_t> finish() {
+    static RansEncoder new_() { return RansEncoder(); }
+    static RansEncoder with_capacity(size_t) { return RansEncoder(); }   // a hint in the reference too
+    RansEncoder() : h_(alice_codec_rans_encoder_new()) { if (!h_) detail::raise(); }
+    RansEncoder(RansEncoder&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    RansEncoder(const RansEncoder&) = delete;
+    ~RansEncoder() { if (h_) alice_codec_rans_encoder_destroy(h_); }
+    void encode(const RansSymbol& sym) { detail::check(alice_codec_rans_encoder_encode(h_, sym.cum_freq, sym.freq)); }          // :269-285
+    void encode_symbols(const std::vector<uint8_t>& symbols, const FrequencyTable& table) {                                    // :288-294
+        if (!symbols.empty())
+            detail::check(alice_codec_rans_encoder_encode_symbols(h_, symbols.data(), symbols.size(), table.cum_freq.data(), table.freq.data()));
+    }
+    std::vector<uint8_t> finish() {   // :298-308, consumes the encoder
         uint64_t n = 0;
-        static const uint8_t empty = 0;
-        uint8_t* p = alice_codec_rans_encode(sym_.empty() ? &empty : sym_.data(), sym_.size(), table_.cum_freq.data(), table_.freq.data(), &n);
+        uint8_t* p = alice_codec_rans_encoder_finish(std::exchange(h_, nullptr), &n);
         if (!p) detail::raise();
         return detail::take(p, n);
     }
 private:
-    std::vector<uint8_t> sym_;
-    FrequencyTable table_ = FrequencyTable{};
+    AliceRansEncoder* h_;
 };
 
-class RansDecoder {  // src/rans.rs:321-389
+class RansDecoder {  // src/rans.rs:321-389: decode / decode_n continue from the current position
 public:
-    explicit RansDecoder(std::vector<uint8_t> input) : in_(std::move(input)) {}
-    std::vector<uint8_t> decode_n(size_t n, const FrequencyTable& table) const {
-        std::vector<uint8_t> out(n);
+    explicit RansDecoder(const std::vector<uint8_t>& input) {
         static const uint8_t empty = 0;
+        h_ = alice_codec_rans_decoder_new(input.empty() ? &empty : input.data(), input.size());
+        if (!h_) detail::raise();
+    }
+    RansDecoder(RansDecoder&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    RansDecoder(const RansDecoder&) = delete;
+    ~RansDecoder() { if (h_) alice_codec_rans_decoder_destroy(h_); }
+    std::vector<uint8_t> decode_n(size_t n, const FrequencyTable& table) {                                                    // :375-381
+        std::vector<uint8_t> out(n);
         uint8_t sink = 0;
-        detail::check(alice_codec_rans_decode(in_.empty() ? &empty : in_.data(), in_.size(), table.cum_freq.data(), table.freq.data(), n,
-                                              n ? out.data() : &sink));
+        detail::check(alice_codec_rans_decoder_decode_n(h_, n, table.cum_freq.data(), table.freq.data(), n ? out.data() : &sink));
         return out;
     }
+    uint8_t decode(const FrequencyTable& table) { return decode_n(1, table)[0]; }                                             // :351-371
+    bool is_empty() const { return alice_codec_rans_decoder_is_empty(h_) != 0; }                                             // :385-389
 private:
-    std::vector<uint8_t> in_;
+    AliceRansDecoder* h_ = nullptr;
 };
 
 class InterleavedRansEncoder {  // src/rans.rs:393-456 (opt-in 4-stream format)

@@ -341,6 +341,69 @@ def rans_decode(data, n: int, table: FrequencyTable, interleaved: bool = False) 
     return out
 
 
+class RansEncoder:
+    """rans.rs:238-309 RansEncoder as an object: encode / encode_symbols may be called any number of times before finish."""
+
+    def __init__(self):
+        L = lib()
+        L.ao_rans_encoder_new.restype = C.c_void_p
+        L.ao_rans_encoder_state.restype = C.c_uint32
+        self._h = C.c_void_p(L.ao_rans_encoder_new())
+
+    def encode(self, cum_freq: int, freq: int) -> None:
+        _check(lib().ao_rans_encoder_encode(self._h, C.c_uint16(cum_freq), C.c_uint16(freq)))
+
+    def encode_symbols(self, symbols, table: FrequencyTable) -> None:
+        s = _u8(symbols).reshape(-1)
+        _check(lib().ao_rans_encoder_encode_symbols(self._h, _ptr(s, _u8p), C.c_size_t(s.size), C.byref(table._t)))
+
+    @property
+    def state(self) -> int:
+        return int(lib().ao_rans_encoder_state(self._h))
+
+    def finish(self) -> bytes:
+        out = _u8p(); n = C.c_size_t()
+        h, self._h = self._h, None
+        _check(lib().ao_rans_encoder_finish(h, C.byref(out), C.byref(n)))
+        return _take(out, n.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ao_rans_encoder_free(self._h)
+
+
+class RansDecoder:
+    """rans.rs:321-389 RansDecoder as an object: decode_n continues from the current position."""
+
+    def __init__(self, data):
+        L = lib()
+        L.ao_rans_decoder_new.restype = C.c_void_p
+        L.ao_rans_decoder_state.restype = C.c_uint32
+        L.ao_rans_decoder_pos.restype = C.c_size_t
+        d = _u8(data).reshape(-1)
+        self._h = C.c_void_p(L.ao_rans_decoder_new(_ptr(d, _u8p), C.c_size_t(d.size)))
+
+    def decode_n(self, n: int, table: FrequencyTable) -> np.ndarray:
+        out = np.zeros(n, np.uint8)
+        lib().ao_rans_decoder_decode_n(self._h, C.c_size_t(n), C.byref(table._t), _ptr(out, _u8p))
+        return out
+
+    def is_empty(self) -> bool:
+        return bool(lib().ao_rans_decoder_is_empty(self._h))
+
+    @property
+    def state(self) -> int:
+        return int(lib().ao_rans_decoder_state(self._h))
+
+    @property
+    def pos(self) -> int:
+        return int(lib().ao_rans_decoder_pos(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ao_rans_decoder_free(self._h)
+
+
 def quality_to_step(q: int) -> int:
     return lib().ao_quality_to_step(q)
 

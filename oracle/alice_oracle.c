@@ -497,6 +497,61 @@ void ao_rans_decode(const uint8_t *in, size_t in_len, size_t n, const ao_freq_ta
     for (size_t i = 0; i < n; ++i) symbols[i] = dec_get(&d, t);
 }
 
+/* ---- the encoder / decoder as OBJECTS that live across calls (src/rans.rs:238-309, 321-389): repeated encode_symbols
+ * and single-symbol encode calls continue one state and one output vector; decode / decode_n continue from the current
+ * position.  The GPU path's stateful handles are checked against these. ---- */
+struct ao_rans_encoder { rans_enc e; };
+struct ao_rans_decoder { rans_dec d; uint8_t *own; };
+
+ao_rans_encoder *ao_rans_encoder_new(void) { /* RansEncoder::new / with_capacity, :249-264 */
+    ao_rans_encoder *h = (ao_rans_encoder *)calloc(1, sizeof(*h));
+    if (h) h->e.state = AO_RANS32_L;
+    return h;
+}
+void ao_rans_encoder_free(ao_rans_encoder *h) {
+    if (h) { free(h->e.buf); free(h); }
+}
+int ao_rans_encoder_encode(ao_rans_encoder *h, uint16_t cum_freq, uint16_t freq) { /* encode(&RansSymbol), :269-285 */
+    return enc_put(&h->e, cum_freq, freq);
+}
+int ao_rans_encoder_encode_symbols(ao_rans_encoder *h, const uint8_t *symbols, size_t n, const ao_freq_table *t) { /* :288-294 */
+    for (size_t i = n; i-- > 0;) {
+        uint8_t s = symbols[i];
+        if ((size_t)s >= t->n_symbols) return AO_ERR_REFERENCE_DIVERGES; /* reference: index out of bounds */
+        int rc = enc_put(&h->e, t->cum_freq[s], t->freq[s]);
+        if (rc) return rc;
+    }
+    return AO_OK;
+}
+uint32_t ao_rans_encoder_state(const ao_rans_encoder *h) { return h->e.state; }
+int ao_rans_encoder_finish(ao_rans_encoder *h, uint8_t **out, size_t *out_len) { /* finish(self), :298-308: consumes the encoder */
+    int rc = enc_finish(&h->e, out, out_len);
+    if (rc == AO_OK) h->e.buf = NULL;
+    ao_rans_encoder_free(h);
+    return rc;
+}
+
+ao_rans_decoder *ao_rans_decoder_new(const uint8_t *in, size_t len) { /* RansDecoder::new, :330-347 (the input is copied) */
+    ao_rans_decoder *h = (ao_rans_decoder *)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->own = (uint8_t *)malloc(len ? len : 1);
+    if (!h->own) { free(h); return NULL; }
+    if (len) memcpy(h->own, in, len);
+    dec_init(&h->d, h->own, len);
+    return h;
+}
+void ao_rans_decoder_free(ao_rans_decoder *h) {
+    if (h) { free(h->own); free(h); }
+}
+void ao_rans_decoder_decode_n(ao_rans_decoder *h, size_t n, const ao_freq_table *t, uint8_t *symbols) { /* :351-381 */
+    for (size_t i = 0; i < n; ++i) symbols[i] = dec_get(&h->d, t);
+}
+int ao_rans_decoder_is_empty(const ao_rans_decoder *h) { /* :385-389 */
+    return h->d.pos >= h->d.len && h->d.state < AO_RANS32_L;
+}
+uint32_t ao_rans_decoder_state(const ao_rans_decoder *h) { return h->d.state; }
+size_t ao_rans_decoder_pos(const ao_rans_decoder *h) { return h->d.pos; }
+
 static void put_u32le(uint8_t *p, uint32_t v) {
     p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
 }

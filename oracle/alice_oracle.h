@@ -107,6 +107,22 @@ int ao_rans_encode(const uint8_t *symbols, size_t n, const ao_freq_table *t, uin
 /* RansDecoder::new + decode_n */
 void ao_rans_decode(const uint8_t *in, size_t in_len, size_t n, const ao_freq_table *t,
                     uint8_t *symbols);
+/* the same coders as objects that live across calls: RansEncoder::{new, encode, encode_symbols, finish} :249-308,
+ * RansDecoder::{new, decode_n, is_empty} :330-389 */
+typedef struct ao_rans_encoder ao_rans_encoder;
+typedef struct ao_rans_decoder ao_rans_decoder;
+ao_rans_encoder *ao_rans_encoder_new(void);
+void ao_rans_encoder_free(ao_rans_encoder *h);
+int ao_rans_encoder_encode(ao_rans_encoder *h, uint16_t cum_freq, uint16_t freq);
+int ao_rans_encoder_encode_symbols(ao_rans_encoder *h, const uint8_t *symbols, size_t n, const ao_freq_table *t);
+uint32_t ao_rans_encoder_state(const ao_rans_encoder *h);
+int ao_rans_encoder_finish(ao_rans_encoder *h, uint8_t **out, size_t *out_len); /* frees h */
+ao_rans_decoder *ao_rans_decoder_new(const uint8_t *in, size_t len);
+void ao_rans_decoder_free(ao_rans_decoder *h);
+void ao_rans_decoder_decode_n(ao_rans_decoder *h, size_t n, const ao_freq_table *t, uint8_t *symbols);
+int ao_rans_decoder_is_empty(const ao_rans_decoder *h);
+uint32_t ao_rans_decoder_state(const ao_rans_decoder *h);
+size_t ao_rans_decoder_pos(const ao_rans_decoder *h);
 int ao_rans_encode_interleaved(const uint8_t *symbols, size_t n, const ao_freq_table *t,
                                uint8_t **out, size_t *out_len);
 int ao_rans_decode_interleaved(const uint8_t *in, size_t in_len, size_t n, const ao_freq_table *t,

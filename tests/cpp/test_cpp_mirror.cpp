@@ -54,6 +54,47 @@ int main(int argc, char** argv) {
     enc.encode_symbols({42, 100, 200}, table);
     auto stream = enc.finish();
     CHECK((ac::RansDecoder(stream).decode_n(3, table) == std::vector<uint8_t>{42, 100, 200}));
+    // the coders are objects that live across calls (src/rans.rs:269-294, 351-381): s1 then s2 == one call on s2 || s1,
+    // single symbols through encode(&RansSymbol), the decoder continues from its position
+    {
+        ac::RansEncoder one = ac::RansEncoder::new_(), two = ac::RansEncoder::with_capacity(64), three = ac::RansEncoder::new_();
+        one.encode_symbols({4, 5, 1, 2, 3}, table);
+        two.encode_symbols({1, 2, 3}, table);
+        two.encode_symbols({4, 5}, table);
+        three.encode_symbols({2, 3}, table);
+        three.encode(table.get_symbol(1));
+        three.encode_symbols({4, 5}, table);
+        auto s1 = one.finish();
+        CHECK(s1 == two.finish() && s1 == three.finish());
+        ac::RansDecoder d(s1);
+        CHECK(!d.is_empty());
+        CHECK((d.decode_n(2, table) == std::vector<uint8_t>{4, 5}));
+        CHECK(d.decode(table) == 1);
+        CHECK((d.decode_n(2, table) == std::vector<uint8_t>{2, 3}));
+        ac::FrequencyTable small = ac::FrequencyTable::uniform(2);      // src/rans.rs:934-944
+        CHECK(small.len() == 2 && small.freq[0] + small.freq[1] == 4096 && small.freq[2] == 0);
+        ac::RansEncoder e2 = ac::RansEncoder::new_();
+        e2.encode_symbols({0, 1, 1, 0, 1}, small);
+        CHECK((ac::RansDecoder(e2.finish()).decode_n(5, small) == std::vector<uint8_t>{0, 1, 1, 0, 1}));
+    }
+    // chunk drivers: one device, and the same device listed twice (two host threads)
+    {
+        std::vector<uint8_t> two = make_gradient(8, 8, 4);
+        auto more = make_gradient(8, 8, 4);
+        for (auto& v : more) v = (uint8_t)(v * 3 + 1);
+        two.insert(two.end(), more.begin(), more.end());
+        ac::FrameEncoder e = ac::FrameEncoder::with_wavelet(80, WaveletType::Cdf97);
+        auto a1 = ac::encode_many(e, two, 8, 8, 4, 2);
+        auto a2 = ac::encode_many(e, two, 8, 8, 4, 2, {0, 0});
+        CHECK(a1.size() == 2 && a2.size() == 2 && a1[0].to_bytes() == a2[0].to_bytes() && a1[1].to_bytes() == a2[1].to_bytes());
+        CHECK(ac::decode_many(a1) == ac::decode_many(a2, {0}));
+        std::vector<int32_t> coeffs = {-100, -7, 0, 7, 100}, qs(5), qb(5), back(5);
+        ac::quantize_subband(coeffs, ac::Quantizer::new_(8), qs);
+        ac::Quantizer::new_(8).quantize_buffer(coeffs, qb);
+        CHECK(qs == qb);
+        ac::dequantize_subband(qs, ac::Quantizer::new_(8), back);
+        CHECK(back[0] == qs[0] * 8 && back[4] == qs[4] * 8);
+    }
     // wavelet doc-test
     std::vector<int32_t> sig = {10, 20, 30, 40, 50, 60, 70, 80};
     ac::Wavelet1D w = ac::Wavelet1D::cdf53();

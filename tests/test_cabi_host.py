@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol(codec):
     lib = codec.load_library()
-    hdr = open(os.path.join(ROOT, "include", "alice_codec.h")).read()
+    import glob
+    hdr = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     names = sorted(set(re.findall(r"\b(alice_codec_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) >= 60
     for n in names:
@@ -209,3 +210,32 @@ def test_encode_reciprocal_is_exact():
         got = ys + q * np.uint64(g) + np.uint64(cb)
         ref = ((ys // np.uint64(f)) << np.uint64(12)) + ys % np.uint64(f) + np.uint64(17)
         assert np.array_equal(got, ref), f
+
+
+def test_many_devices_plan_is_round_robin(codec):
+    """alice_codec_many_devices_plan: chunk k -> devices[k mod n] (src/pipeline.rs:461-497: chunks are independent), in
+    chunk order; no device is touched, so this runs without a GPU."""
+    assert codec.plan_devices(7, [0, 1, 2]) == [0, 1, 2, 0, 1, 2, 0]
+    assert codec.plan_devices(5, [3]) == [3] * 5
+    assert codec.plan_devices(4, [1, 1, 0]) == [1, 1, 0, 1]          # a device may be listed twice (two host threads)
+    assert codec.plan_devices(0, [0, 1]) == []
+    assert codec.plan_devices(3, list(range(8))) == [0, 1, 2]
+    for bad in ([], [-1], [0, -2]):
+        with pytest.raises(codec.CodecError) as e:
+            codec.plan_devices(4, bad)
+        assert e.value.kind == "DeviceError"
+
+
+def test_many_devices_validate_before_touching_a_gpu(codec):
+    """Argument errors of the multi-device calls come back in the reference's order and need no device."""
+    lib = codec.load_library()
+    enc = lib.alice_codec_encoder_create(80)
+    devs = (C.c_int * 2)(0, 1)
+    out = (C.c_void_p * 2)()
+    buf = (C.c_uint8 * 10)()
+    assert lib.alice_codec_encode_many_devices(enc, buf, 10, 4, 4, 2, 2, devs, 2, out) == 1      # InvalidBufferSize
+    assert lib.alice_codec_encode_many_devices(enc, buf, 0, 0, 4, 2, 2, devs, 2, out) == 2       # InvalidDimensions
+    assert lib.alice_codec_encode_many_devices(None, buf, 10, 4, 4, 2, 2, devs, 2, out) == 9     # null
+    assert lib.alice_codec_encode_many_devices(enc, buf, 0, 4, 4, 2, 0, devs, 2, out) == 0       # no chunks: nothing to do
+    assert lib.alice_codec_decode_many_devices(None, 1, devs, 2, buf, 10) == 9
+    lib.alice_codec_encoder_destroy(enc)
