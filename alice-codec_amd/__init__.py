@@ -139,7 +139,7 @@ def load_library() -> C.CDLL:
         "alice_codec_test_force_first_cap": (None, [C.c_uint64]),
         "alice_codec_test_last_decode_stats": (None, [_u32p]),
         "alice_codec_test_chain_occupancy": (C.c_int, [_u32p]),
-        "alice_codec_test_set_tuning": (None, [C.c_long, C.c_long, C.c_long]),
+        "alice_codec_test_set_tuning": (None, [C.c_long]),
         "alice_codec_test_transform_ms": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
                                                     C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_float), vp]),
         "alice_codec_encoder_create_ex": (vp, [C.c_uint8, C.c_uint8]),

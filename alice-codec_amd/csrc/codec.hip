@@ -189,6 +189,16 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+// Entry points that run on a CALLER's stream name it here for the duration of the call: buffers allocated meanwhile
+// remember it (DevBuf::alloc) and drain it before they go back to the pool.  Cleared on return, so that a later call of
+// the same thread never tags its buffers with a stream the caller may have destroyed since.
+struct ScopeStream {
+    explicit ScopeStream(hipStream_t s) { tl_scope_stream = s; }
+    ~ScopeStream() { tl_scope_stream = nullptr; }
+    ScopeStream(const ScopeStream&) = delete;
+    ScopeStream& operator=(const ScopeStream&) = delete;
+};
+
 // Entry points that work on an object tied to a device (a batch) switch this thread to it for the call.
 struct DeviceScope {
     int saved;
@@ -446,43 +456,45 @@ struct StageEvents {
     ~StageEvents() { if (ready) for (auto& e : ev) (void)hipEventDestroy(e); }
 };
 
-// Encode of n_chunks chunks on `st`; results stay on the device.  Phase A (transforms) is followed by one
-// host round trip that sizes the stream regions from the histograms (cap_override != 0 skips that and
-// forces a capacity, used by the overflow retry); phase B (tables, chains, assembly) is asynchronous.
+// Encode of n_chunks chunks on `st`; results stay on the device.  How the stream regions are sized:
+//   kCapReuse    the work area already owns .alc buffers (a batch after its first encode): keep their capacities and
+//                queue everything without touching the host -- the chains check their regions, and a chunk that outgrew
+//                them (new content) comes back as an overflow, which the caller answers with kCapEstimate;
+//   kCapEstimate one host round trip between the transforms and the chains reads the histograms and derives a capacity
+//                per channel (estimate_stream_cap); also what kCapReuse falls back to when there are no buffers yet;
+//   kCapWorst    2 bytes per symbol, the bound of the format (the last resort: 3 x 2 x padded bytes per chunk).
+enum CapMode { kCapReuse = 0, kCapEstimate = 1, kCapWorst = 2 };
 int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wavelet, hipStream_t st,
-                  StageEvents* evs, uint64_t cap_override = 0) {
+                  StageEvents* evs, CapMode mode = kCapReuse) {
     const ChunkDims& d = w.d;
     const int32_t step = quality_to_step(quality);
     const int B = w.n_chunks;
     HIP_TRY(hipMemsetAsync(w.hist.p, 0, (size_t)B * 3 * 256 * sizeof(uint32_t), st));
     if (evs) HIP_TRY(hipEventRecord(evs->ev[0], st));
-    {
-        // chunk after chunk through one pipe: the temporal pass of a chunk's last band shares a launch with the tile
-        // pass of the next chunk's first band
-        ForwardPipe pipe;
-        for (int b = 0; b < B; ++b) {
-            const uint8_t* rgb = d_rgb + (size_t)b * d.n_pixels * 3;
-            uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
-            uint32_t* hist = w.hist.as<uint32_t>() + (size_t)b * 3 * 256;
-            if (!w.scratch.p || !pipe.enqueue(rgb, d, wavelet, step, w.scratch.p, sym, hist, st)) {
-                pipe.flush(st);
-                TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
-            }
-        }
-        pipe.flush(st);
+    for (int b = 0; b < B; ++b) {
+        const uint8_t* rgb = d_rgb + (size_t)b * d.n_pixels * 3;
+        uint8_t* sym = w.sym.as<uint8_t>() + (size_t)b * 3 * d.padded;
+        uint32_t* hist = w.hist.as<uint32_t>() + (size_t)b * 3 * 256;
+        if (!w.scratch.p || !launch_forward_transform(rgb, d, wavelet, step, w.scratch.p, sym, hist, st))
+            TRY(forward_generic(rgb, d, wavelet, step, w, sym, hist, st));
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[1], st));
-    uint64_t cap[3] = {cap_override, cap_override, cap_override};
-    if (!cap_override) {
+    const bool had_alc = w.alc.p != nullptr;
+    uint64_t cap[3] = {w.cap[0], w.cap[1], w.cap[2]};
+    if (mode == kCapWorst) {
+        cap[0] = cap[1] = cap[2] = worst_cap(d);
+    } else if (mode == kCapEstimate || !had_alc) {
+        cap[0] = cap[1] = cap[2] = 0;
         std::vector<uint32_t> hist((size_t)B * 3 * 256);
         HIP_TRY(hipMemcpyAsync(hist.data(), w.hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         // one capacity per channel (the largest over the chunks): Y streams are about twice as long as Co / Cg streams
         for (int c = 0; c < 3 * B; ++c) cap[c % 3] = std::max(cap[c % 3], estimate_stream_cap(&hist[(size_t)c * 256], d.padded));
         for (int c = 0; c < 3; ++c) cap[c] = std::min(round_up(cap[c], 256), worst_cap(d));
-        // test-only override (alice_codec_test_force_first_cap): pretend the estimate was far too small, to exercise
-        // the overflow-and-retry path
-        if (const uint64_t forced = tl_test_first_cap) cap[0] = cap[1] = cap[2] = forced;
+        // test-only override (alice_codec_test_force_first_cap): pretend the first estimate was far too small, to
+        // exercise the overflow-and-retry path
+        if (mode == kCapReuse && !had_alc)
+            if (const uint64_t forced = tl_test_first_cap) cap[0] = cap[1] = cap[2] = forced;
     }
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
@@ -608,17 +620,13 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
     if (evs) HIP_TRY(hipEventRecord(evs->ev[6], st));
     {
         const bool tiles = transform_tiles_eligible(d) && w.scratch->p;
-        InversePipe pipe;
         for (int b = 0; b < B; ++b) {
             int32_t step[3] = {headers[b].ch[0].quant_step, headers[b].ch[1].quant_step, headers[b].ch[2].quant_step};
             const InverseBounds ib = inverse_bounds(headers[b].wavelet, step);
             const uint8_t* sym = w.sym_ptr + (size_t)b * 3 * d.padded;
-            if (!tiles || !pipe.enqueue(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.scratch->p, d_rgb[b], st)) {
-                pipe.flush(st);
+            if (!tiles || !launch_inverse_transform(sym, d, headers[b].wavelet, step, !ib.fast, ib.fast && ib.mid16, ib.fast && ib.lds16, w.scratch->p, d_rgb[b], st))
                 TRY(inverse_generic(sym, d, headers[b].wavelet, step, w, d_rgb[b], st));
-            }
         }
-        pipe.flush(st);
     }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[7], st));
     HIP_TRY(hipGetLastError());
@@ -685,10 +693,10 @@ int encode_host(const FrameEncoder& enc, const uint8_t* rgb, uint64_t rgb_len, u
     std::vector<RansResult> res;
     TRY(encode_work_alloc(w, d, 1));
     for (int attempt = 0;; ++attempt) {
-        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, attempt ? worst_cap(d) : 0));
+        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt));
         int rc = encode_collect(w, st, res);
         if (rc == kOk) break;
-        if (rc != -1 || attempt > 0) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
+        if (rc != -1 || attempt >= 2) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
     }
     uint64_t payload = res[0].len + res[1].len + res[2].len;
     std::vector<uint8_t> alc((size_t)kAlcHeaderBytes + payload);
@@ -977,6 +985,7 @@ AliceBatch* alice_codec_batch_create(uint32_t width, uint32_t height, uint32_t f
     const ChunkDims d = make_dims(width, height, frames);
     if (d.padded > 0xFFFFFFFFull) { fail(kDimensionOverflow, "padded pixel count exceeds u32"); return nullptr; }
     if (ensure_device()) return nullptr;
+    tl_scope_stream = nullptr;   // the batch's buffers outlive every call: no stream of this thread's past belongs on them
     AliceBatch* b = new (std::nothrow) AliceBatch();
     if (!b) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
     b->d = d; b->n_chunks = n_chunks; b->quality = quality; b->wavelet = wavelet_type; b->device = tl_device;
@@ -991,6 +1000,7 @@ void alice_codec_batch_destroy(AliceBatch* b) {
         DeviceScope ds(b->device);
         if (ds.ok) (void)hipDeviceSynchronize();
         b->enc_stream = b->dec_stream = nullptr;
+        tl_scope_stream = nullptr;
     }
     delete b;
 }
@@ -1014,8 +1024,10 @@ int alice_codec_batch_encode_finish(AliceBatch* b, uint64_t* sizes) {
     tl_scope_stream = nullptr;
     std::vector<RansResult> res;
     int rc = encode_collect(b->enc, b->enc_stream, res);
-    if (rc == -1 && b->last_rgb) {  // capacity estimate exceeded (never observed): run again with the worst case
-        TRY(encode_launch(b->last_rgb, b->enc, b->quality, b->wavelet, b->enc_stream, &b->evs, worst_cap(b->d)));
+    // a chain outgrew its region: the capacities came from an earlier encode of other content (kCapReuse) -- size them
+    // from this content's histograms and run again; should even that fall short (never observed), take the format's bound
+    for (int mode = kCapEstimate; rc == -1 && b->last_rgb && mode <= kCapWorst; ++mode) {
+        TRY(encode_launch(b->last_rgb, b->enc, b->quality, b->wavelet, b->enc_stream, &b->evs, (CapMode)mode));
         rc = encode_collect(b->enc, b->enc_stream, res);
     }
     if (rc == -1) return fail(kInternal, "rANS output exceeded the worst-case capacity");
@@ -1033,6 +1045,20 @@ const void* alice_codec_batch_alc_ptr(const AliceBatch* b, uint32_t chunk) {
 }
 uint64_t alice_codec_batch_alc_stride(const AliceBatch* b) { return b ? b->enc.alc_stride : 0; }
 const void* alice_codec_batch_symbols_ptr(const AliceBatch* b) { return b ? b->enc.sym.p : nullptr; }
+// device memory the batch holds per chunk (symbols = decoded pixels, the .alc buffer at its current capacities, tables,
+// histograms, results of both directions) and independent of the chunk count (transform scratch, the spare pixel buffer
+// of a banded in-place decode): what a caller needs to size a batch to the free HBM
+uint64_t alice_codec_batch_bytes_per_chunk(const AliceBatch* b) {
+    if (!b) return 0;
+    const uint64_t tables = 3ull * (sizeof(RansTable) + 256 * sizeof(uint32_t) + sizeof(RansResult));
+    return 3 * b->d.padded + b->enc.alc_stride + 2 * tables + 3 * sizeof(RansDecodeDesc) + sizeof(unsigned long long);
+}
+uint64_t alice_codec_batch_fixed_bytes(const AliceBatch* b) {
+    if (!b) return 0;
+    uint64_t n = (uint64_t)b->enc.scratch.n + (16u << 20);   // + allocation granules of the small buffers
+    if (transform_tiles_eligible(b->d) && inverse_cuts_chunk(b->d)) n += b->d.n_pixels * 3;
+    return n;
+}
 uint64_t alice_codec_batch_padded_pixels(const AliceBatch* b) { return b ? b->d.padded : 0; }
 
 int alice_codec_batch_pack_alc(AliceBatch* b, const uint64_t* sizes, void* d_dst, uint64_t dst_capacity, void* hip_stream) {
@@ -1079,15 +1105,18 @@ int alice_codec_batch_decode(AliceBatch* b, const void* d_alc, uint64_t alc_stri
         TRY(validate_for_decode(headers[i], &dd, payload));
         pay[i] = (const uint8_t*)d_alc + (size_t)i * alc_stride + kAlcHeaderBytes;
     }
-    // d_rgb_out == NULL: the batch keeps the pixels in its own storage (alice_codec_batch_rgb_ptr).  The launches work band
-    // by band, so the tile pass of a chunk's first band writes pixels while the temporal pass of its later bands still
-    // reads symbols: the pixels of chunk i therefore land on the symbols of chunk i - 1, whose last reader (its own
-    // temporal pass) finished launches ago, and chunk 0 gets a buffer of its own.
+    // d_rgb_out == NULL: the batch keeps the pixels in its own storage (alice_codec_batch_rgb_ptr).  An uncut chunk is
+    // reconstructed over its own (by then consumed) symbols: its temporal pass is the last reader of those symbols and
+    // runs before the tile pass that writes the pixels.  A chunk that is cut into bands writes the pixels of its first
+    // band while the temporal pass of its later bands still reads symbols: the pixels of chunk i then land on the symbols
+    // of chunk i - 1, whose last reader finished launches ago, and chunk 0 gets a buffer of its own.
     b->rgb_dst.assign(b->n_chunks, nullptr);
     if (!d_rgb_out) {
-        if (!b->spare.p) TRY(b->spare.alloc(b->d.n_pixels * 3));
+        const bool cut = inverse_cuts_chunk(b->d);
+        if (cut && !b->spare.p) TRY(b->spare.alloc(b->d.n_pixels * 3));
         for (uint32_t i = 0; i < b->n_chunks; ++i)
-            b->rgb_dst[i] = i == 0 ? b->spare.as<uint8_t>() : b->dec.sym_ptr + (size_t)(i - 1) * 3 * b->d.padded;
+            b->rgb_dst[i] = !cut ? b->dec.sym_ptr + (size_t)i * 3 * b->d.padded
+                                 : (i == 0 ? b->spare.as<uint8_t>() : b->dec.sym_ptr + (size_t)(i - 1) * 3 * b->d.padded);
     } else {
         for (uint32_t i = 0; i < b->n_chunks; ++i) b->rgb_dst[i] = (uint8_t*)d_rgb_out + (size_t)i * b->d.n_pixels * 3;
     }
@@ -1688,11 +1717,11 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
             if (hipMemcpyAsync(d_rgb.as<uint8_t>() + (size_t)i * chunk_bytes, rgb[first + i], chunk_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
                 return undo(fail(kDeviceError, "host to device copy failed"));
         for (int attempt = 0;; ++attempt) {
-            rc = encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, attempt ? worst_cap(d) : 0);
+            rc = encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt);
             if (rc != kOk) return undo(rc);
             rc = encode_collect(w, st, res);
             if (rc == kOk) break;
-            if (rc != -1 || attempt > 0) return undo(rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc);
+            if (rc != -1 || attempt >= 2) return undo(rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc);
         }
         std::vector<uint8_t> alc;
         for (uint32_t i = 0; i < B; ++i) {
@@ -1905,7 +1934,7 @@ int alice_codec_dev_forward_symbols(const void* d_rgb, uint32_t width, uint32_t 
     if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count exceeds u32");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
-    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
+    ScopeStream scope(st);   // temporaries drain the caller's stream before they return to the pool
     EncodeWork w;
     w.d = d; w.n_chunks = 1;
     const bool tiles = transform_tiles_eligible(d);
@@ -1933,7 +1962,7 @@ int alice_codec_dev_inverse_symbols(const void* d_symbols, uint32_t width, uint3
     if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count exceeds u32");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
-    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
+    ScopeStream scope(st);   // temporaries drain the caller's stream before they return to the pool
     DecodeWork w;
     w.d = d; w.n_chunks = 1;
     const InverseBounds ib = inverse_bounds(wavelet_type, step);
@@ -1972,7 +2001,7 @@ int alice_codec_dev_histogram(const void* d_symbols, uint64_t n, void* d_hist, v
     if (!d_hist || (!d_symbols && n)) return fail(kNullArgument, "null argument");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
-    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
+    ScopeStream scope(st);   // temporaries drain the caller's stream before they return to the pool
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(uint32_t), st));
     if (n) launch_histogram((const uint8_t*)d_symbols, n, (uint32_t*)d_hist, st);
     HIP_TRY(hipGetLastError());
@@ -1994,7 +2023,7 @@ int alice_codec_dev_rans_encode(const void* d_symbols, uint64_t n, const uint32_
     if (cap < 4 + 64 + 64) return fail(kInvalidBufferSize, "stream region too small");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
-    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
+    ScopeStream scope(st);   // temporaries drain the caller's stream before they return to the pool
     DevBuf dh, dt, dres;
     TRY(dh.alloc(256 * 4)); TRY(dt.alloc(sizeof(RansTable))); TRY(dres.alloc(sizeof(RansResult)));
     HIP_TRY(hipMemcpyAsync(dh.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
@@ -2019,7 +2048,7 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
     if (!n) return kOk;
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
-    tl_scope_stream = st;   // temporaries drain the caller's stream before they return to the pool
+    ScopeStream scope(st);   // temporaries drain the caller's stream before they return to the pool
     DevBuf dh, dt, ddesc, dres;
     TRY(dh.alloc(256 * 4)); TRY(dt.alloc(sizeof(RansTable))); TRY(ddesc.alloc(sizeof(RansDecodeDesc))); TRY(dres.alloc(sizeof(RansResult)));
     HIP_TRY(hipMemcpyAsync(dh.p, hist, 256 * 4, hipMemcpyHostToDevice, st));
@@ -2038,7 +2067,7 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
 
 // ---- test and measurement hooks (include/alice_codec_test.h) ----
 
-void alice_codec_test_set_tuning(long band_kb, long t_blocks, long no_fuse) { set_transform_tuning(band_kb, t_blocks, no_fuse); }
+void alice_codec_test_set_tuning(long band_kb) { set_transform_tuning(band_kb); }
 
 int alice_codec_test_chain_occupancy(uint32_t out[6]) {
     clear_error();
@@ -2061,7 +2090,7 @@ int alice_codec_test_transform_ms(const void* d_rgb, void* d_sym, void* d_rgb_ou
     if (!transform_tiles_eligible(d)) return fail(kInvalidDimensions, "shape runs the generic path: nothing to time");
     TRY(ensure_device());
     hipStream_t st = (hipStream_t)hip_stream;
-    tl_scope_stream = st;
+    ScopeStream scope(st);
     const int32_t step = quality_to_step(quality);
     const int32_t steps[3] = {step, step, step};
     const InverseBounds ib = inverse_bounds(wavelet_type, steps);
@@ -2073,22 +2102,18 @@ int alice_codec_test_transform_ms(const void* d_rgb, void* d_sym, void* d_rgb_ou
     TRY(ev.init());
     set_transform_probe(probe);
     auto fwd = [&]() {
-        ForwardPipe pipe;
         for (uint32_t c = 0; c < n_chunks; ++c) {
             const uint32_t k = c % n_buffers;
-            pipe.enqueue((const uint8_t*)d_rgb + (size_t)k * d.n_pixels * 3, d, wavelet_type, step, scratch.p,
-                         (uint8_t*)d_sym + (size_t)k * 3 * d.padded, hist.as<uint32_t>(), st);
+            launch_forward_transform((const uint8_t*)d_rgb + (size_t)k * d.n_pixels * 3, d, wavelet_type, step, scratch.p,
+                                     (uint8_t*)d_sym + (size_t)k * 3 * d.padded, hist.as<uint32_t>(), st);
         }
-        pipe.flush(st);
     };
     auto inv = [&]() {
-        InversePipe pipe;
         for (uint32_t c = 0; c < n_chunks; ++c) {
             const uint32_t k = c % n_buffers;
-            pipe.enqueue((const uint8_t*)d_sym + (size_t)k * 3 * d.padded, d, wavelet_type, steps, !ib.fast, ib.fast && ib.mid16,
-                         ib.fast && ib.lds16, scratch.p, (uint8_t*)d_rgb_out + (size_t)k * d.n_pixels * 3, st);
+            launch_inverse_transform((const uint8_t*)d_sym + (size_t)k * 3 * d.padded, d, wavelet_type, steps, !ib.fast, ib.fast && ib.mid16,
+                                     ib.fast && ib.lds16, scratch.p, (uint8_t*)d_rgb_out + (size_t)k * d.n_pixels * 3, st);
         }
-        pipe.flush(st);
     };
     fwd();   // warm-up; also leaves real symbols for the inverse
     hipError_t e = hipEventRecord(ev.ev[0], st);

@@ -18,7 +18,11 @@ Register plan (all literal, all listed as clobbers by the including statement):
   s[60:61]    {window copy : x} shift pair      s[62:63] 64-bit big-endian byte window      s[64:65] refill pair
   s67 F'   s69 B'   s70 product   s71 shift   s72 valid window bits - 33   s73 next window dword
   s74 blocks left   s75 byte-swap selector   s76 row   s77 shift of the odd symbol   s78 scratch
-  s80..s100   renormalisation shift (0, 8 or 16) by count-leading-zeros of the state
+  s79..s99    renormalisation shift (0, 8 or 16) by count-leading-zeros of the state (0 .. 20: the updated state is at
+              least 2^11).  Not s100 and up: the compiler keeps those for itself and ignores them in a clobber list.
+  s59         M0 of the surrounding code.  M0 is written by every s_set_gpr_idx_on (the row) and by s_flbit (the index of
+              s_movrels); the compiler reserves it and does not honour an "m0" clobber, so the statement saves it first and
+              restores it last -- whatever the compiler keeps in M0 survives, and the clobber lists need not name it.
 Operands: %[tp] (SGPR pair: the chain's RansDecSlots in global memory, F' then B'), %[l4] (VGPR: 4 * lane),
           %[wa] (VGPR: per-lane LDS byte address of the window), %[ra] (VGPR in/out: record address, 2 B per lane),
           %[xi] %[pi] %[nb] (SGPR in), %[xo] %[po] (SGPR out).
@@ -33,10 +37,13 @@ REC = 192 + WIN_ROWS
 L = []
 def e(s): L.append(s)
 
+M0_SAVE = "s59"
+
 def table_loads(emit):
     """F' then B' (contiguous in RansDecSlots): 128 rows of 256 bytes, row r into v[64 + r], lane l <- dword 64 r + l.
     global_load's immediate offset is 13 bits signed, so the scalar base moves on every 16 rows (the address is read
     when the load issues)."""
+    emit(f"s_mov_b32 {M0_SAVE}, m0")
     emit("s_mov_b64 s[64:65], %[tp]")
     for r in range(128):
         emit(f"global_load_dword v{64 + r}, %[l4], s[64:65] offset:{256 * (r % 16)}")
@@ -53,7 +60,7 @@ for r in range(WIN_ROWS):
     e(f"v_perm_b32 v{192 + r}, v{192 + r}, v{192 + r}, s75")
 for c in range(21):
     sh = 0 if c <= 8 else (8 if c <= 16 else 16)
-    e(f"s_mov_b32 s{80 + c}, {sh}")
+    e(f"s_mov_b32 s{79 + c}, {sh}")
 # scalar state: x, 64-bit window primed with two dwords
 e("s_mov_b32 s61, %[xi]")
 e("s_mov_b32 s74, %[nb]")
@@ -97,7 +104,7 @@ for lane in range(64):
     # one instruction must sit between the SALU write of M0 and s_movrels (wait state): the copy for the even symbol,
     # a no-op for the odd one
     e("s_mov_b32 s60, s63" if not lane & 1 else "s_nop 0")
-    e(f"s_movrels_b32 {sh}, s80")
+    e(f"s_movrels_b32 {sh}, s79")
     e(f"s_lshl_b64 s[60:61], s[60:61], {sh}")
     if lane & 1:
         e("s_add_u32 s78, s71, s77")
@@ -131,6 +138,7 @@ e("s_lshr_b32 s71, s71, 3")
 e("s_sub_u32 %[po], s70, s71")
 e("s_mov_b32 %[xo], s61")
 e("s_waitcnt lgkmcnt(0)")
+e(f"s_mov_b32 m0, {M0_SAVE}")
 
 # ---- "dry" tile: the stream is exhausted (pos >= len), so the reference's refill loop reads nothing any more
 # (src/rans.rs:365-368) and the state simply evolves: the same lookup and update, no window, no shift.
@@ -159,9 +167,10 @@ d("s_cmp_lg_u32 s74, 0")
 d("s_cbranch_scc1 2b")
 d("s_mov_b32 %[xo], s61")
 d("s_waitcnt lgkmcnt(0)")
-dry_clob = ["memory", "scc", "m0", "s61", "s64", "s65", "s67", "s69", "s70", "s74", "s76"] + [f"v{r}" for r in range(64, 192)] + [f"v{REC}"]
+d(f"s_mov_b32 m0, {M0_SAVE}")
+dry_clob = ["memory", "scc", "s59", "s61", "s64", "s65", "s67", "s69", "s70", "s74", "s76"] + [f"v{r}" for r in range(64, 192)] + [f"v{REC}"]
 
-clob = ["memory", "scc", "m0"] + [f"s{i}" for i in range(60, 79)] + [f"s{80 + c}" for c in range(21)]
+clob = ["memory", "scc"] + [f"s{i}" for i in range(59, 79)] + [f"s{79 + c}" for c in range(21)]
 clob += [f"v{r}" for r in range(64, REC + 1)]
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rans_decode_tile.inc")
 with open(out, "w") as f:

@@ -81,73 +81,31 @@ bool chain_kernel_occupancy(uint32_t out[6]);
 // after the inverse temporal pass) stays in the Infinity Cache between the two passes, and every launch runs the
 // temporal role of one band beside the tile role of its neighbour (transform.hip, "Band-ordered, role-fused launches").
 struct BandPlan {
-    int tile_h, tiles_y;   // tile height of the tile role, tile rows of the frame
+    int tile_h, tiles_y;   // tile height of the tile pass, tile rows of the frame
     int tpb, n_bands;      // tile rows per band, bands (1 = the frame is not cut)
-    int slots;             // band slots the scratch holds (2 when cut: producer and consumer of neighbouring bands overlap)
-    size_t slot_bytes;
+    size_t slot_bytes;     // scratch the launches of one chunk need
 };
 // false: the shape needs the generic path -- a padded width or height below 6 (the tile kernels read their halo
 // through one reflection), a frame of more than 2^30 samples (32-bit offsets inside a frame), or more tiles than a
 // 1-D grid holds.
 bool transform_tiles_eligible(const ChunkDims& d);
-// scratch (band slots) the forward / inverse launches of a chunk of this shape need; the caller owns the buffer
+// scratch (one band slot) the forward / inverse launches of a chunk of this shape need; the caller owns the buffer
 size_t forward_scratch_bytes(const ChunkDims& d);
 size_t inverse_scratch_bytes(const ChunkDims& d, bool mid16);
-
-struct FwdXy; struct FwdTm; struct InvXy; struct InvTm;   // role arguments (transform.hip)
-
-// Enqueues the launches of chunk after chunk on one stream.  The temporal role of a chunk's last band stays pending and
-// rides in the first launch of the next chunk (flush() runs it alone), so a batch of chunks never drains the device
-// between chunks.  hist: uint32 [3][256], zeroed by the caller.  enqueue returns false (nothing launched) when the shape
-// needs the generic path.  All chunks that share launches must use the same scratch buffer.
-class ForwardPipe {
-public:
-    ForwardPipe();
-    ~ForwardPipe();
-    ForwardPipe(const ForwardPipe&) = delete;
-    ForwardPipe& operator=(const ForwardPipe&) = delete;
-    bool enqueue(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step, void* d_scratch, uint8_t* d_sym,
-                 uint32_t* d_hist, hipStream_t st);
-    void flush(hipStream_t st);
-private:
-    void launch(const FwdXy* xa, const FwdTm* ta, hipStream_t st);
-    FwdTm* pending_;
-    bool has_pending_ = false;
-    int ns_ = 0, slot_ = 0;
-    bool step1_ = false;
-    void* scratch_ = nullptr;
-    size_t slot_bytes_ = 0;
-};
-// steps per channel come from the chunk header.  exact = 64-bit lifting products.  mid16 = the intermediate after the
-// temporal pass provably fits i16 (halves its traffic); lds16 = so does everything after the column pass (packed tile).
-// Here the pending role is the tile role of the chunk's last band (it writes d_rgb: the chunk's pixels are complete
-// only after the next enqueue or flush).
-class InversePipe {
-public:
-    InversePipe();
-    ~InversePipe();
-    InversePipe(const InversePipe&) = delete;
-    InversePipe& operator=(const InversePipe&) = delete;
-    bool enqueue(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3], bool exact, bool mid16,
-                 bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st);
-    void flush(hipStream_t st);
-private:
-    void launch(const InvXy* xa, const InvTm* ta, hipStream_t st);
-    InvXy* pending_;
-    bool has_pending_ = false;
-    int ns_ = 0, slot_ = 0, variant_ = -1;
-    void* scratch_ = nullptr;
-    size_t slot_bytes_ = 0;
-};
+bool inverse_cuts_chunk(const ChunkDims& d);   // the inverse launches of this shape work band by band (see launch_inverse_transform)
 // measurement only (alice_codec_test_transform_ms): the calling thread's next launches of the CDF 9/7 instances run their
-// VALU-floor twins (same instruction streams, global loads and stores replaced by register moves)
-void set_transform_probe(int mode);   // 0 off, 1 loads and stores replaced, 2 loads only, 3 stores only
-// tuning of the band plan (negative = keep): slot target in KiB (0 = never cut), cap on the temporal role's workgroups per
-// launch (0 = no cap), 1 = every role in a launch of its own.  Process-wide; meant for tests and probes.
-void set_transform_tuning(long band_kb, long t_blocks, long no_fuse);
-// one chunk, both roles flushed: enqueue + flush
+// probe twins: 0 off, 1 loads and stores replaced by register moves (the VALU floor), 2 loads only, 3 stores only
+void set_transform_probe(int mode);
+// target size of a band slot in KiB (0 = never cut; negative = keep).  Process-wide; meant for tests and probes.
+void set_transform_tuning(long band_kb);
+// Launches of one chunk on `st`, band after band (tile pass then temporal pass; the inverse the other way round).
+// hist: uint32 [3][256], zeroed by the caller.  Returns false (nothing launched) when the shape needs the generic path.
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
                               void* d_scratch, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st);
+// steps per channel come from the chunk header.  exact = 64-bit lifting products.  mid16 = the intermediate after the
+// temporal pass provably fits i16 (halves its traffic); lds16 = so does everything after the column pass (packed tile).
+// When the chunk is cut into bands the pixels of the first band are written while the symbols of later bands are still
+// unread: d_rgb must not overlap d_sym then (an uncut chunk may decode over its own symbols).
 bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
                               bool exact, bool mid16, bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st);
 

@@ -110,24 +110,23 @@ __device__ __forceinline__ void lift_regs(int (&v)[N], const Coeffs& cf) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Band-ordered, role-fused launches (round 3)
+// Bands
 //
-// The spatial (tile) kernels are bound by instruction issue, the temporal kernels by memory, and between them sits
-// the i16 intermediate: 6 B/px written once and read once, 796 MB per 1080p x 64 chunk -- three times the 256 MiB
-// Infinity Cache.  So a chunk is cut into BANDS of whole tile rows (all frames of those rows), small enough for the
-// band's intermediate to stay on the die between its producer and its consumer, and every launch carries TWO roles:
-//     forward   launch j = { temporal pass of band j-1 (memory)  ||  tile pass of band j (issue) }
-//     inverse   launch j = { temporal pass of band j   (memory)  ||  tile pass of band j-1 (issue) }
-// The roles of one launch touch different band slots of a two-slot ring, so stream order between launches is the only
-// synchronisation; the temporal role's workgroups come first in the grid (they are few and long-running and start at
-// once), the tile role's workgroups stream through the remaining slots of every CU.  The last role of a chunk stays
-// pending and is fused with the first launch of the next chunk (ForwardPipe / InversePipe), so a batch never drains.
-// A band's rows are [low-band rows | high-band rows] of the y-deinterleaved plane; inside the band slot they are
-// contiguous, so the temporal role reads (writes) the slot linearly and maps a pixel to its place in the symbol plane
-// through two segment bases.  The inverse band carries two halo rows of each half on either side (the temporal pass
-// simply covers them: it is per pixel), so its tile role depends on its own band only.
+// Between the spatial (tile) pass and the temporal pass sits the i16 intermediate: 6 B/px, 796 MB per 1080p x 64 chunk,
+// 12.7 GB per 8K x 64 chunk.  A chunk may therefore be cut into BANDS of whole tile rows (all frames of those rows): the
+// tile pass and the temporal pass of one band run back to back on a band-sized slot, then the next band reuses the slot.
+// A band's rows are [low-band rows | high-band rows] of the y-deinterleaved plane; inside the slot they are contiguous,
+// so the temporal pass reads (writes) the slot linearly and maps a pixel to its place in the symbol plane through two
+// segment bases.  The inverse band carries two halo rows of each half on either side (the temporal pass simply covers
+// them: it is per pixel), so its tile pass depends on its own band only.
 // Shapes that cannot be cut (a padded width that is not a multiple of 4: a segment would not be a whole number of
 // 4-pixel groups) run as ONE band = the whole frame, where both mappings are the identity.
+// What bands are for is MEMORY (the scratch of large frames), not speed.  Round 3 measured the alternatives on 1080p x 64
+// (profiles/r03_transform_sweep.json): bands small enough to keep the slot in the 256 MiB Infinity Cache, with the two
+// passes of neighbouring bands fused into one launch (temporal role || tile role), are 3-30 % SLOWER than the uncut
+// chunk -- both passes turn out to be bound by vector-instruction issue (the VALU-floor probe: 0.51 / 0.43 ms with
+// every global access removed, against 0.69 / 0.64 ms), so running them side by side buys nothing, and the many small
+// launches cost their tails.  The default therefore cuts only when the uncut intermediate would exceed 1 GiB.
 // ------------------------------------------------------------------------------------------------
 
 // one band of a chunk as the tile role sees it
@@ -136,15 +135,12 @@ struct BandTiles {
     int ix0, ix1, iy0, iy1;      // the interior rectangle of the FRAME in tile coordinates (halo inside the frame)
 };
 
-// logical block of the tile role -> tile.  XCD-aware order: the role's blocks start at a multiple of 8 and are padded to
-// a multiple of 8, so (b & 7) is still the XCD and XCD k takes the k-th contiguous eighth of the sequence
-// (frame-major, then tile row, then tile).
-__device__ __forceinline__ bool band_tile_of_block(const BandTiles& bt, unsigned frames, unsigned role_block, unsigned role_blocks,
-                                                   int& bx, int& by, int& t, bool& edge) {
-    const unsigned per_xcd = role_blocks >> 3;
-    const unsigned l = (role_block & 7u) * per_xcd + (role_block >> 3);
+// workgroup -> tile.  XCD-aware order (xcd_logical_block): XCD k takes the k-th contiguous eighth of the sequence
+// (frame-major, then tile row, then tile), so a tile's neighbours hit in the same L2.
+__device__ __forceinline__ bool band_tile_of_block(const BandTiles& bt, unsigned frames, int& bx, int& by, int& t, bool& edge) {
     const unsigned per_frame = (unsigned)(bt.nx * bt.nby);
-    if (l >= per_frame * frames) return false;
+    const unsigned l = xcd_logical_block(per_frame * frames);
+    if (l == 0xFFFFFFFFu) return false;
     t = (int)(l / per_frame);
     const int i = (int)(l % per_frame);
     bx = i % bt.nx; by = bt.by0 + i / bt.nx;
@@ -271,7 +267,7 @@ __device__ __forceinline__ void fwd_xy_tile(const FwdXy& a, int bx, int by, int 
                     else out[(size_t)yy * pw] = (int16_t)v[H + k];
                 }
             }
-            if ((PROBE & 2) && acc == 0x5EEDF00D) out[0] = (int16_t)acc;
+            if ((PROBE & 2) && acc == 0x5EEDF00D) a.mid[0] = (int16_t)acc;   // (keeps the checksum alive; a valid address whatever the tile)
         }
     }
 }
@@ -451,15 +447,15 @@ struct FwdT {
     }
 };
 
-// The temporal role's view of a band.  A unit is one workgroup's worth of 4-pixel groups of one channel; a role
-// workgroup takes units rb, rb + n_blocks, ... (units are channel-major, so it changes channel at most twice).
+// The temporal pass's view of a band.  A unit is one workgroup's worth of 4-pixel groups of one channel; the grid has one
+// workgroup per unit (units are channel-major).
 struct BandT {
     uint32_t pf;                 // padded frames
     uint32_t band_px;            // pixels of the band per frame = rows * pw (a multiple of 4)
     uint32_t seg_px;             // pixels of its low-row half; the rest are the high rows
     uint32_t lo_base, hi_base;   // where those halves start inside a frame of the chunk's (deinterleaved) plane
     uint64_t plane;              // pw * ph
-    uint32_t units_per_ch, n_blocks;
+    uint32_t units_per_ch;
 };
 // pixel index of a slot-linear pixel inside the chunk's plane (identity when the band is the whole frame)
 __device__ __forceinline__ uint32_t band_plane_index(const BandT& b, uint32_t idx) {
@@ -475,59 +471,41 @@ struct FwdTm {
     BandT b;
 };
 
-template <int NS, bool STEP1, int THREADS, int PROBE = 0>
-__device__ __forceinline__ void fwd_t_role(const FwdTm& a, unsigned rb, uint32_t* lh) {
+template <int NS, bool STEP1, int PROBE = 0>
+__global__ __launch_bounds__(256) void fwd_t_kernel(FwdTm a) {
+    __shared__ uint32_t lh[kHistWords];
     const int tid = threadIdx.x;
-    if (rb >= a.b.n_blocks) return;
-    for (int i = tid; i < kHistWords; i += THREADS) lh[i] = 0u;
+    for (int i = tid; i < kHistWords; i += 256) lh[i] = 0u;
     __syncthreads();
-    int cur_ch = -1;
-    auto fold = [&](int ch) {
-        __syncthreads();
-        if (tid < 256) {
-            // fold the replicas of bin `tid` (rotated start: the threads read 32 different banks)
-            uint32_t cnt = 0u;
-#pragma unroll 8
-            for (int r = 0; r < kHistReplicas; ++r) cnt += lh[tid * kHistReplicas + ((r + tid) & (kHistReplicas - 1))];
-            if (cnt) atomicAdd(&a.hist[ch * 256 + tid], cnt);
-        }
-    };
-    for (uint32_t unit = rb; unit < 3u * a.b.units_per_ch; unit += a.b.n_blocks) {
-        const int ch = (int)(unit / a.b.units_per_ch);
-        const uint32_t blk = unit % a.b.units_per_ch;
-        if (ch != cur_ch && cur_ch >= 0) {       // uniform per workgroup
-            fold(cur_ch);
-            __syncthreads();
-            for (int i = tid; i < kHistWords; i += THREADS) lh[i] = 0u;
-            __syncthreads();
-        }
-        cur_ch = ch;
-        const uint32_t idx = (blk * (uint32_t)THREADS + (uint32_t)tid) * 4u;
-        if (idx < a.b.band_px) {
-            FwdT<NS, STEP1, true, PROBE> f;
-            f.src = (const char*)(a.mid + (size_t)ch * a.b.pf * a.b.band_px);
-            f.dst = (char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
-            f.plane_s = a.b.band_px; f.plane_d = a.b.plane;
-            f.off16 = idx * 2u; f.off8 = band_plane_index(a.b, idx);
-            f.half = (int)a.b.pf / 2; f.cf = a.cf; f.hdz = a.hdz; f.magic = a.magic; f.lane_rep = (uint32_t)tid & 31u; f.lh = lh;
-            f.run();
-        }
+    const int ch = (int)(blockIdx.x / a.b.units_per_ch);
+    const uint32_t blk = blockIdx.x % a.b.units_per_ch;
+    const uint32_t idx = (blk * 256u + (uint32_t)tid) * 4u;
+    if (idx < a.b.band_px) {
+        FwdT<NS, STEP1, true, PROBE> f;
+        f.src = (const char*)(a.mid + (size_t)ch * a.b.pf * a.b.band_px);
+        f.dst = (char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
+        f.plane_s = a.b.band_px; f.plane_d = a.b.plane;
+        f.off16 = idx * 2u; f.off8 = band_plane_index(a.b, idx);
+        f.half = (int)a.b.pf / 2; f.cf = a.cf; f.hdz = a.hdz; f.magic = a.magic; f.lane_rep = (uint32_t)tid & 31u; f.lh = lh;
+        f.run();
     }
-    if (cur_ch >= 0) fold(cur_ch);
+    __syncthreads();
+    // fold the replicas of bin `tid` (rotated start: the 256 threads read 32 different banks)
+    uint32_t cnt = 0u;
+#pragma unroll 8
+    for (int r = 0; r < kHistReplicas; ++r) cnt += lh[tid * kHistReplicas + ((r + tid) & (kHistReplicas - 1))];
+    if (cnt) atomicAdd(&a.hist[ch * 256 + tid], cnt);
 }
 
-// the forward launch: temporal role of the previous band in blocks [0, n_t), tile role of this band behind them
-template <int NS, bool STEP1, int PROBE = 0>
-__global__ __launch_bounds__(F_THREADS) void fwd_band_kernel(FwdXy xa, FwdTm ta, unsigned n_t) {
+// (probe twins: border tiles need the clamping index map while the loads are real and the bounds tests while the stores
+// are real; only with both replaced can the interior instance serve every tile)
+template <int NS, int PROBE = 0>
+__global__ __launch_bounds__(F_THREADS) void fwd_xy_kernel(FwdXy xa) {
     extern __shared__ int lds[];
-    const unsigned b = blockIdx.x;
-    if (b < n_t) { fwd_t_role<NS, STEP1, F_THREADS, PROBE>(ta, b, (uint32_t*)lds); return; }
     int bx, by, t;
     bool edge;
-    if (!band_tile_of_block(xa.bt, (unsigned)xa.d.pf, b - n_t, gridDim.x - n_t, bx, by, t, edge)) return;
-    // (border tiles need the clamping index map whenever the loads are real; with the loads replaced the interior
-    // instance serves every tile)
-    if (edge && !(PROBE & 1)) fwd_xy_tile<NS, true, PROBE>(xa, bx, by, t, lds);
+    if (!band_tile_of_block(xa.bt, (unsigned)xa.d.pf, bx, by, t, edge)) return;
+    if (edge && PROBE != 3) fwd_xy_tile<NS, true, PROBE>(xa, bx, by, t, lds);
     else fwd_xy_tile<NS, false, PROBE>(xa, bx, by, t, lds);
 }
 
@@ -661,31 +639,29 @@ struct InvTm {
     BandT b;                     // band_px = slot pixels per frame; lo_base / hi_base = L0 * pw / (hh + L0) * pw
 };
 
-template <int NS, bool EXACT, typename MidT, int THREADS, int PROBE = 0>
-__device__ __forceinline__ void inv_t_role(const InvTm& a, unsigned rb, int* luts /* 3 * 256 */) {
+template <int NS, bool EXACT, typename MidT, int PROBE = 0>
+__global__ __launch_bounds__(256) void inv_t_kernel(InvTm a) {
+    __shared__ int lut[256];
     const int tid = threadIdx.x;
-    if (rb >= a.b.n_blocks) return;
-    for (int i = tid; i < 3 * 256; i += THREADS) {
-        const int s = i & 255;
+    const int ch = (int)(blockIdx.x / a.b.units_per_ch);
+    const uint32_t blk = blockIdx.x % a.b.units_per_ch;
+    {
+        const int s = tid;
         const int q = (s == 0) ? 0 : ((s & 1) ? (s + 1) / 2 : -(s / 2));      // src/quant.rs:581-587
-        luts[i] = (int)((unsigned)q * (unsigned)a.step[i >> 8]);              // src/quant.rs:104-110 (wrapping)
+        lut[s] = (int)((unsigned)q * (unsigned)a.step[ch]);                   // src/quant.rs:104-110 (wrapping)
     }
     __syncthreads();
-    for (uint32_t unit = rb; unit < 3u * a.b.units_per_ch; unit += a.b.n_blocks) {
-        const int ch = (int)(unit / a.b.units_per_ch);
-        const uint32_t blk = unit % a.b.units_per_ch;
-        const uint32_t idx = (blk * (uint32_t)THREADS + (uint32_t)tid) * 4u;
-        if (idx >= a.b.band_px) continue;
-        InvT<NS, EXACT, MidT, PROBE> f;
-        f.src = (const char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
-        f.dst = (MidT*)a.mid + (size_t)ch * a.b.pf * a.b.band_px + idx;
-        f.plane_s = a.b.plane; f.plane_d = a.b.band_px;
-        f.off8 = band_plane_index(a.b, idx);
-        f.half = (int)a.b.pf / 2; f.nf = (int)a.nf;
-        f.c0 = -a.cf.c[0]; f.c1 = -a.cf.c[1]; f.c2 = -a.cf.c[2]; f.c3 = -a.cf.c[3];
-        f.lut = luts + ch * 256;
-        f.run();
-    }
+    const uint32_t idx = (blk * 256u + (uint32_t)tid) * 4u;
+    if (idx >= a.b.band_px) return;
+    InvT<NS, EXACT, MidT, PROBE> f;
+    f.src = (const char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
+    f.dst = (MidT*)a.mid + (size_t)ch * a.b.pf * a.b.band_px + idx;
+    f.plane_s = a.b.plane; f.plane_d = a.b.band_px;
+    f.off8 = band_plane_index(a.b, idx);
+    f.half = (int)a.b.pf / 2; f.nf = (int)a.nf;
+    f.c0 = -a.cf.c[0]; f.c1 = -a.cf.c[1]; f.c2 = -a.cf.c[2]; f.c3 = -a.cf.c[3];
+    f.lut = lut;
+    f.run();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,7 +737,7 @@ __device__ __forceinline__ void store_rgb8(const InvXy& a, bool edge, const int*
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             acc ^= ((uint32_t)out[4 * i] | ((uint32_t)out[4 * i + 1] << 8) | ((uint32_t)out[4 * i + 2] << 16) | ((uint32_t)out[4 * i + 3] << 24)) + (uint32_t)i;
-        if (acc == 0x5EEDF00Du) *(uint32_t*)p = acc;
+        if (acc == 0x5EEDF00Du) *a.rgb = (uint8_t)acc;   // (keeps the checksum alive; a valid address whatever the tile)
     } else if (a.aligned && (!edge || gxs + 8 <= (int)d.w)) {
         uint32_t* p4 = (uint32_t*)p;
 #pragma unroll
@@ -922,24 +898,21 @@ __device__ __forceinline__ void inv_xy_tile_dpp(const InvXy& a, int bx, int by, 
     }
 }
 
-// the inverse launch: temporal role of this band in blocks [0, n_t), tile role of the previous band behind them.
 // PACKED = the packed-i16 recompute tile (384 threads); otherwise the lane-exchange tile (512 threads).
 template <bool PACKED> struct InvTileShape { static constexpr int kThreads = PACKED ? I_THREADS : X_THREADS;
                                              static constexpr int kLdsInts = PACKED ? 3 * ((I_TH + 8) / 2) * I_LW : 3 * (X_TH + 8) * X_LW; };
 
 template <int NS, bool EXACT, typename MidT, bool PACKED, int PROBE = 0>
-__global__ __launch_bounds__(InvTileShape<PACKED>::kThreads) void inv_band_kernel(InvXy xa, InvTm ta, unsigned n_t) {
+__global__ __launch_bounds__(InvTileShape<PACKED>::kThreads) void inv_xy_kernel(InvXy xa) {
     __shared__ __attribute__((aligned(16))) int lds[InvTileShape<PACKED>::kLdsInts];
-    const unsigned b = blockIdx.x;
-    if (b < n_t) { inv_t_role<NS, EXACT, MidT, InvTileShape<PACKED>::kThreads, PROBE>(ta, b, lds); return; }
     int bx, by, t;
     bool edge;
-    if (!band_tile_of_block(xa.bt, xa.d.f, b - n_t, gridDim.x - n_t, bx, by, t, edge)) return;
+    if (!band_tile_of_block(xa.bt, xa.d.f, bx, by, t, edge)) return;
     if (PACKED) {
         if (edge) inv_xy_tile_packed<NS, true, EXACT, MidT>(xa, bx, by, t, lds);
         else inv_xy_tile_packed<NS, false, EXACT, MidT>(xa, bx, by, t, lds);
     } else {
-        if (edge && !(PROBE & 1)) inv_xy_tile_dpp<NS, true, EXACT, MidT, PROBE>(xa, bx, by, t, lds);
+        if (edge && PROBE != 3) inv_xy_tile_dpp<NS, true, EXACT, MidT, PROBE>(xa, bx, by, t, lds);
         else inv_xy_tile_dpp<NS, false, EXACT, MidT, PROBE>(xa, bx, by, t, lds);
     }
 }
@@ -1160,25 +1133,15 @@ static bool set_dyn_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
-// Tuning, settable by the test hook alice_codec_test_set_tuning and, for developer runs, by the environment at first
-// use: ALICE_BAND_KB = target size of a band slot in KiB (0 = never cut a chunk into bands), ALICE_T_BLOCKS = cap on the
-// temporal role's workgroups per launch (0 = one per unit), ALICE_NO_FUSE = 1 gives every role a launch of its own.
-static long env_long(const char* name, long dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atol(v) : dflt;
+// Target size of a band slot in KiB (0 = never cut a chunk into bands).  Default 1 GiB: 1080p x 64 chunks stay whole,
+// 4K x 64 chunks run in 4 bands, 8K x 64 chunks in 13 (see "Bands").  Settable by alice_codec_test_set_tuning (the suite
+// runs small shapes through many bands) and, for developer runs, by ALICE_BAND_KB at first use.
+static long& band_target_kb() {
+    static long kb = [] { const char* v = getenv("ALICE_BAND_KB"); return (v && *v) ? atol(v) : 1024L * 1024L; }();
+    return kb;
 }
-struct TransformTuning { long band_kb, t_blocks, no_fuse; };
-static TransformTuning& tuning() {
-    static TransformTuning t{env_long("ALICE_BAND_KB", 64 * 1024), env_long("ALICE_T_BLOCKS", 512), env_long("ALICE_NO_FUSE", 0)};
-    return t;
-}
-void set_transform_tuning(long band_kb, long t_blocks, long no_fuse) {
-    TransformTuning& t = tuning();
-    if (band_kb >= 0) t.band_kb = band_kb;
-    if (t_blocks >= 0) t.t_blocks = t_blocks;
-    if (no_fuse >= 0) t.no_fuse = no_fuse;
-}
-// alice_codec_test_transform_ms(probe = 1): the CDF 9/7, step > 1, i16 lane-exchange instances run their VALU-floor twins
+void set_transform_tuning(long band_kb) { if (band_kb >= 0) band_target_kb() = band_kb; }
+// alice_codec_test_transform_ms(probe != 0): the CDF 9/7, step > 1, i16 lane-exchange instances run their probe twins
 static thread_local int tl_valu_probe = 0;
 void set_transform_probe(int mode) { tl_valu_probe = mode; }
 
@@ -1190,97 +1153,67 @@ bool transform_tiles_eligible(const ChunkDims& d) {
 }
 
 // Band plan of a chunk for tiles of tile_h rows: bands of `tpb` tile rows (the last one takes what is left).  Cut only
-// when the padded width is a multiple of 4 (see the header comment) and there are at least two bands' worth of rows.
+// when the padded width is a multiple of 4 (see "Bands") and there are at least two bands' worth of rows.
 BandPlan plan_bands(const ChunkDims& d, int tile_h, size_t bytes_per_sample, int halo_rows) {
     BandPlan p{};
     p.tile_h = tile_h;
     p.tiles_y = (int)((d.ph + tile_h - 1) / tile_h);
     const size_t row_bytes = (size_t)d.pw * d.pf * 3 * bytes_per_sample;     // one padded row of all frames and channels
     long tpb = p.tiles_y;
-    const long target = tuning().band_kb;
+    const long target = band_target_kb();
     if (target > 0 && d.pw % 4 == 0) {
         tpb = (long)(((size_t)target << 10) / (row_bytes * (size_t)tile_h));
         if (tpb < 1) tpb = 1;
         if (tpb * 2 > p.tiles_y) tpb = p.tiles_y;                            // fewer than two bands: do not cut
     }
-    p.tpb = (int)tpb;
+    p.n_bands = (int)((p.tiles_y + tpb - 1) / tpb);
+    p.tpb = (p.tiles_y + p.n_bands - 1) / p.n_bands;                         // bands of equal height (no sliver at the end)
     p.n_bands = (p.tiles_y + p.tpb - 1) / p.tpb;
     // rows a slot holds: the band's own rows (+ the halo rows of the inverse band on either side), or the whole frame
     const size_t slot_rows = p.n_bands > 1 ? std::min<size_t>((size_t)p.tpb * tile_h, d.ph) + (size_t)2 * halo_rows : d.ph;
     p.slot_bytes = ((slot_rows * row_bytes + 255) / 256) * 256 + 256;
-    p.slots = p.n_bands > 1 ? 2 : 1;
     return p;
 }
 
-size_t forward_scratch_bytes(const ChunkDims& d) {
-    const BandPlan p = plan_bands(d, F_TH, sizeof(int16_t), 0);
-    return p.slot_bytes * p.slots;
-}
+size_t forward_scratch_bytes(const ChunkDims& d) { return plan_bands(d, F_TH, sizeof(int16_t), 0).slot_bytes; }
 size_t inverse_scratch_bytes(const ChunkDims& d, bool mid16) {
-    const BandPlan p = plan_bands(d, I_TH, mid16 ? sizeof(int16_t) : sizeof(int32_t), 4);
-    return p.slot_bytes * p.slots;
+    return plan_bands(d, I_TH, mid16 ? sizeof(int16_t) : sizeof(int32_t), 4).slot_bytes;
 }
 
-static BandT make_band_t(const ChunkDims& d, uint32_t band_px, uint32_t seg_px, uint32_t lo_base, uint32_t hi_base, int threads) {
+// whether the inverse launches of a chunk of this shape work band by band (either sample width)
+bool inverse_cuts_chunk(const ChunkDims& d) {
+    return plan_bands(d, I_TH, sizeof(int16_t), 4).n_bands > 1 || plan_bands(d, I_TH, sizeof(int32_t), 4).n_bands > 1;
+}
+
+static BandT make_band_t(const ChunkDims& d, uint32_t band_px, uint32_t seg_px, uint32_t lo_base, uint32_t hi_base) {
     BandT b{};
     b.pf = (uint32_t)d.pf; b.band_px = band_px; b.seg_px = seg_px; b.lo_base = lo_base; b.hi_base = hi_base;
     b.plane = d.pw * d.ph;
-    b.units_per_ch = (band_px + (uint32_t)threads * 4u - 1u) / ((uint32_t)threads * 4u);
-    const long cap = tuning().t_blocks;
-    b.n_blocks = 3u * b.units_per_ch;
-    if (cap > 0 && b.n_blocks > (uint32_t)cap) b.n_blocks = (uint32_t)cap;
+    b.units_per_ch = (band_px + 1023u) / 1024u;      // 256 threads x 4 pixels
     return b;
 }
 
-static inline unsigned round_up8(unsigned v) { return (v + 7u) & ~7u; }
-
 // ---- forward ----
 
-template <int NS, bool STEP1, int PROBE = 0>
-static void fwd_band_launch(const FwdXy* xa, const FwdTm* ta, hipStream_t st) {
-    static const bool ok = set_dyn_lds(fwd_band_kernel<NS, STEP1, PROBE>, (size_t)3 * (F_TH + 2 * NS) * F_LP * sizeof(int));
+template <int NS, int PROBE = 0>
+static void fwd_xy_launch(const FwdXy& xa, hipStream_t st) {
+    const size_t lds = (size_t)3 * (F_TH + 2 * NS) * F_LP * sizeof(int);
+    static const bool ok = set_dyn_lds(fwd_xy_kernel<NS, PROBE>, lds);
     (void)ok;
-    const size_t lds = (size_t)3 * (F_TH + 2 * NS) * F_LP * sizeof(int);   // >= the 32 KB of histogram replicas of the temporal role
-    static_assert(3 * (F_TH + 4) * F_LP * sizeof(int) >= kHistWords * sizeof(uint32_t), "tile LDS must hold the histogram replicas");
-    FwdXy x0{}; FwdTm t0{};
-    const unsigned n_t = ta ? round_up8(ta->b.n_blocks) : 0u;
-    const unsigned long long tiles = xa ? (unsigned long long)xa->bt.nx * xa->bt.nby * xa->d.pf : 0ull;
-    const unsigned n_xy = xcd_grid(tiles);
-    if (n_t + n_xy == 0) return;
-    hipLaunchKernelGGL((fwd_band_kernel<NS, STEP1, PROBE>), dim3(n_t + n_xy), dim3(F_THREADS), lds, st, xa ? *xa : x0, ta ? *ta : t0, n_t);
+    const unsigned long long tiles = (unsigned long long)xa.bt.nx * xa.bt.nby * xa.d.pf;
+    hipLaunchKernelGGL((fwd_xy_kernel<NS, PROBE>), dim3(xcd_grid(tiles)), dim3(F_THREADS), lds, st, xa);
+}
+template <int NS, bool STEP1, int PROBE = 0>
+static void fwd_t_launch(const FwdTm& ta, hipStream_t st) {
+    hipLaunchKernelGGL((fwd_t_kernel<NS, STEP1, PROBE>), dim3(3u * ta.b.units_per_ch), dim3(256), 0, st, ta);
 }
 
-void ForwardPipe::launch(const FwdXy* xa, const FwdTm* ta, hipStream_t st) {
-    if (tuning().no_fuse && xa && ta) { launch(nullptr, ta, st); launch(xa, nullptr, st); return; }
-    if (ns_ == 4 && !step1_ && tl_valu_probe) {
-        if (tl_valu_probe == 1) fwd_band_launch<4, false, 3>(xa, ta, st);        // loads and stores replaced
-        else if (tl_valu_probe == 2) fwd_band_launch<4, false, 1>(xa, ta, st);   // loads replaced
-        else fwd_band_launch<4, false, 2>(xa, ta, st);                           // stores replaced
-        return;
-    }
-    if (ns_ == 4) { if (step1_) fwd_band_launch<4, true>(xa, ta, st); else fwd_band_launch<4, false>(xa, ta, st); }
-    else { if (step1_) fwd_band_launch<2, true>(xa, ta, st); else fwd_band_launch<2, false>(xa, ta, st); }
-}
-
-ForwardPipe::ForwardPipe() : pending_(new FwdTm()) {}
-ForwardPipe::~ForwardPipe() { delete pending_; }
-
-void ForwardPipe::flush(hipStream_t st) {
-    if (!has_pending_) return;
-    launch(nullptr, pending_, st);
-    has_pending_ = false;
-}
-
-bool ForwardPipe::enqueue(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step, void* scratch,
-                          uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
+bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
+                              void* d_scratch, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
     if (step < 1 || step > 64) return false;
     if (!transform_tiles_eligible(d)) return false;
     const LiftSteps ls = lift_steps(wavelet);
     const BandPlan bp = plan_bands(d, F_TH, sizeof(int16_t), 0);
-    // the fused launch runs both roles with one set of template arguments, and the two-slot ring assumes one slot size
-    const bool same = has_pending_ && ns_ == ls.n && step1_ == (step == 1) && scratch == scratch_ && bp.slot_bytes == slot_bytes_ && bp.slots == 2;
-    if (!same) flush(st);
-    ns_ = ls.n; step1_ = step == 1; scratch_ = scratch; slot_bytes_ = bp.slot_bytes;
     const Coeffs cf = to_coeffs(ls);
     const unsigned nx = (unsigned)((d.pw + F_TW - 1) / F_TW), ny = (unsigned)bp.tiles_y;
     // a tile is interior when its loaded range [gx0-4, gx0+128+4) x [gy0-H, gy0+40+H) lies inside w x h
@@ -1291,88 +1224,51 @@ bool ForwardPipe::enqueue(const uint8_t* d_rgb, const ChunkDims& d, int wavelet,
     while (iy1 < ny && interior_y(iy1)) ++iy1;
     const uint32_t magic = step == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint32_t)step - 1u) / (uint32_t)step);
     const uint32_t hh = (uint32_t)(d.ph / 2), pw = (uint32_t)d.pw;
+    const int probe = (ls.n == 4 && step != 1) ? tl_valu_probe : 0;
     for (int band = 0; band < bp.n_bands; ++band) {
         const int by0 = band * bp.tpb, nby = std::min(bp.tpb, bp.tiles_y - by0);
         const int y0 = by0 * F_TH, rows = (int)std::min<uint64_t>((uint64_t)(by0 + nby) * F_TH, d.ph) - y0;
-        if (bp.slots == 2) slot_ ^= 1; else slot_ = 0;
-        int16_t* mid = (int16_t*)((char*)scratch + (size_t)slot_ * bp.slot_bytes);
         FwdXy xa{};
-        xa.rgb = d_rgb; xa.mid = mid; xa.d = d; xa.cf = cf;
+        xa.rgb = d_rgb; xa.mid = (int16_t*)d_scratch; xa.d = d; xa.cf = cf;
         xa.aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
         xa.bt = BandTiles{(int)nx, by0, nby, 1, (int)ix1, 1, (int)iy1};
         xa.y0 = y0; xa.rows = rows;
-        launch(&xa, has_pending_ ? pending_ : nullptr, st);
-        FwdTm& ta = *pending_;
-        ta.mid = mid; ta.sym = d_sym; ta.hist = d_hist; ta.cf = cf; ta.hdz = (uint32_t)step / 2u; ta.magic = magic;
-        ta.b = make_band_t(d, (uint32_t)rows * pw, (uint32_t)(rows / 2) * pw, (uint32_t)(y0 / 2) * pw, (hh + (uint32_t)(y0 / 2)) * pw, F_THREADS);
-        has_pending_ = true;
+        FwdTm ta{};
+        ta.mid = (const int16_t*)d_scratch; ta.sym = d_sym; ta.hist = d_hist; ta.cf = cf; ta.hdz = (uint32_t)step / 2u; ta.magic = magic;
+        ta.b = make_band_t(d, (uint32_t)rows * pw, (uint32_t)(rows / 2) * pw, (uint32_t)(y0 / 2) * pw, (hh + (uint32_t)(y0 / 2)) * pw);
+        if (probe) {   // loads and stores replaced / loads only / stores only
+            if (probe == 1) { fwd_xy_launch<4, 3>(xa, st); fwd_t_launch<4, false, 3>(ta, st); }
+            else if (probe == 2) { fwd_xy_launch<4, 1>(xa, st); fwd_t_launch<4, false, 1>(ta, st); }
+            else { fwd_xy_launch<4, 2>(xa, st); fwd_t_launch<4, false, 2>(ta, st); }
+        } else if (ls.n == 4) {
+            fwd_xy_launch<4>(xa, st);
+            if (step == 1) fwd_t_launch<4, true>(ta, st); else fwd_t_launch<4, false>(ta, st);
+        } else {
+            fwd_xy_launch<2>(xa, st);
+            if (step == 1) fwd_t_launch<2, true>(ta, st); else fwd_t_launch<2, false>(ta, st);
+        }
     }
-    if (bp.slots == 1) flush(st);   // an uncut chunk owns the whole scratch: its temporal pass cannot wait for the next chunk
-    return true;
-}
-
-bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,
-                              void* d_scratch, uint8_t* d_sym, uint32_t* d_hist, hipStream_t st) {
-    ForwardPipe p;
-    if (!p.enqueue(d_rgb, d, wavelet, step, d_scratch, d_sym, d_hist, st)) return false;
-    p.flush(st);
     return true;
 }
 
 // ---- inverse ----
 
 template <int NS, bool EXACT, typename MidT, bool PACKED, int PROBE = 0>
-static void inv_band_launch(const InvXy* xa, const InvTm* ta, hipStream_t st) {
-    InvXy x0{}; InvTm t0{};
-    const unsigned n_t = ta ? round_up8(ta->b.n_blocks) : 0u;
-    const unsigned long long tiles = xa ? (unsigned long long)xa->bt.nx * xa->bt.nby * xa->d.f : 0ull;
-    const unsigned n_xy = xcd_grid(tiles);
-    if (n_t + n_xy == 0) return;
-    hipLaunchKernelGGL((inv_band_kernel<NS, EXACT, MidT, PACKED, PROBE>), dim3(n_t + n_xy), dim3(InvTileShape<PACKED>::kThreads), 0, st,
-                       xa ? *xa : x0, ta ? *ta : t0, n_t);
+static void inv_band_launch(const InvTm& ta, const InvXy& xa, hipStream_t st) {
+    hipLaunchKernelGGL((inv_t_kernel<NS, EXACT, MidT, PROBE>), dim3(3u * ta.b.units_per_ch), dim3(256), 0, st, ta);
+    const unsigned long long tiles = (unsigned long long)xa.bt.nx * xa.bt.nby * xa.d.f;
+    hipLaunchKernelGGL((inv_xy_kernel<NS, EXACT, MidT, PACKED, PROBE>), dim3(xcd_grid(tiles)), dim3(InvTileShape<PACKED>::kThreads), 0, st, xa);
 }
 
-void InversePipe::launch(const InvXy* xa, const InvTm* ta, hipStream_t st) {
-    if (tuning().no_fuse && xa && ta) { launch(nullptr, ta, st); launch(xa, nullptr, st); return; }
-    // variant: 0 exact (i32), 1 fast i32, 2 fast i16 lane-exchange tile, 3 fast i16 packed tile
-    if (ns_ == 4 && variant_ == 2 && tl_valu_probe) {
-        if (tl_valu_probe == 1) inv_band_launch<4, false, int16_t, false, 3>(xa, ta, st);
-        else if (tl_valu_probe == 2) inv_band_launch<4, false, int16_t, false, 1>(xa, ta, st);
-        else inv_band_launch<4, false, int16_t, false, 2>(xa, ta, st);
-        return;
-    }
-#define ALICE_INV(NS_) \
-    switch (variant_) { \
-    case 0: inv_band_launch<NS_, true, int32_t, false>(xa, ta, st); break; \
-    case 1: inv_band_launch<NS_, false, int32_t, false>(xa, ta, st); break; \
-    case 2: inv_band_launch<NS_, false, int16_t, false>(xa, ta, st); break; \
-    default: inv_band_launch<NS_, false, int16_t, true>(xa, ta, st); break; \
-    }
-    if (ns_ == 4) { ALICE_INV(4) } else { ALICE_INV(2) }
-#undef ALICE_INV
-}
-
-InversePipe::InversePipe() : pending_(new InvXy()) {}
-InversePipe::~InversePipe() { delete pending_; }
-
-void InversePipe::flush(hipStream_t st) {
-    if (!has_pending_) return;
-    launch(pending_, nullptr, st);
-    has_pending_ = false;
-}
-
-bool InversePipe::enqueue(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3], bool exact, bool mid16,
-                          bool lds16, void* scratch, uint8_t* d_rgb, hipStream_t st) {
+bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
+                              bool exact, bool mid16, bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st) {
     if (!transform_tiles_eligible(d)) return false;
     const LiftSteps ls = lift_steps(wavelet);
     // mid16: the host proved every value after the inverse temporal pass fits i16 (then exact is false too);
-    // lds16: also after the inverse column pass (packed tile)
+    // lds16: also after the inverse column pass (packed tile).
+    // variant: 0 exact (i32), 1 fast i32, 2 fast i16 lane-exchange tile, 3 fast i16 packed tile
     const int variant = exact ? 0 : (mid16 ? (lds16 ? 3 : 2) : 1);
-    const bool m16 = variant >= 2;
-    const BandPlan bp = plan_bands(d, I_TH, m16 ? sizeof(int16_t) : sizeof(int32_t), 4);
-    const bool same = has_pending_ && ns_ == ls.n && variant_ == variant && scratch == scratch_ && bp.slot_bytes == slot_bytes_ && bp.slots == 2;
-    if (!same) flush(st);
-    ns_ = ls.n; variant_ = variant; scratch_ = scratch; slot_bytes_ = bp.slot_bytes;
+    const BandPlan bp = plan_bands(d, I_TH, variant >= 2 ? sizeof(int16_t) : sizeof(int32_t), 4);
     const Coeffs cf = to_coeffs(ls);
     const unsigned nx = (d.w + I_TW - 1) / I_TW, ny = (d.h + I_TH - 1) / I_TH;   // tiles over the REAL frame (every pixel written exists)
     // a tile is interior when the range it reads, [gx0 - 4, gx0 + 96 + 4) x [gy0 - 4, gy0 + 32 + 4), lies inside w x h
@@ -1385,6 +1281,7 @@ bool InversePipe::enqueue(const uint8_t* d_sym, const ChunkDims& d, int wavelet,
     const int hh = (int)(d.ph / 2);
     const uint32_t pw = (uint32_t)d.pw;
     const int n_bands = bp.n_bands > 1 ? ((int)ny + bp.tpb - 1) / bp.tpb : 1;
+    const int probe = (ls.n == 4 && variant == 2) ? tl_valu_probe : 0;
     for (int band = 0; band < n_bands; ++band) {
         const int by0 = n_bands > 1 ? band * bp.tpb : 0, nby = n_bands > 1 ? std::min(bp.tpb, (int)ny - by0) : (int)ny;
         // slot rows: the band's own rows plus two halo rows of each half on either side, inside the frame
@@ -1394,29 +1291,30 @@ bool InversePipe::enqueue(const uint8_t* d_sym, const ChunkDims& d, int wavelet,
             L0 = std::max(0, Y0 / 2 - 2); L1 = std::min(hh, Y1 / 2 + 2);
         }
         const int rows_l = L1 - L0;
-        if (bp.slots == 2) slot_ ^= 1; else slot_ = 0;
-        void* mid = (char*)scratch + (size_t)slot_ * bp.slot_bytes;
         InvTm ta{};
-        ta.sym = d_sym; ta.mid = mid; ta.cf = cf; ta.step[0] = step[0]; ta.step[1] = step[1]; ta.step[2] = step[2]; ta.nf = d.f;
-        ta.b = make_band_t(d, 2u * (uint32_t)rows_l * pw, (uint32_t)rows_l * pw, (uint32_t)L0 * pw, (uint32_t)(hh + L0) * pw,
-                           variant == 3 ? I_THREADS : X_THREADS);
-        launch(has_pending_ ? pending_ : nullptr, &ta, st);
-        InvXy& xa = *pending_;
-        xa.mid = mid; xa.rgb = d_rgb; xa.d = d; xa.cf = cf;
+        ta.sym = d_sym; ta.mid = d_scratch; ta.cf = cf; ta.step[0] = step[0]; ta.step[1] = step[1]; ta.step[2] = step[2]; ta.nf = d.f;
+        ta.b = make_band_t(d, 2u * (uint32_t)rows_l * pw, (uint32_t)rows_l * pw, (uint32_t)L0 * pw, (uint32_t)(hh + L0) * pw);
+        InvXy xa{};
+        xa.mid = d_scratch; xa.rgb = d_rgb; xa.d = d; xa.cf = cf;
         xa.aligned = (d.w % 4 == 0) && ((((uintptr_t)d_rgb) & 3u) == 0u);
         xa.bt = BandTiles{(int)nx, by0, nby, 1, (int)ix1, 1, (int)iy1};
         xa.L0 = L0; xa.rows_l = rows_l;
-        has_pending_ = true;
+        if (probe) {
+            if (probe == 1) inv_band_launch<4, false, int16_t, false, 3>(ta, xa, st);
+            else if (probe == 2) inv_band_launch<4, false, int16_t, false, 1>(ta, xa, st);
+            else inv_band_launch<4, false, int16_t, false, 2>(ta, xa, st);
+            continue;
+        }
+#define ALICE_INV(NS_) \
+        switch (variant) { \
+        case 0: inv_band_launch<NS_, true, int32_t, false>(ta, xa, st); break; \
+        case 1: inv_band_launch<NS_, false, int32_t, false>(ta, xa, st); break; \
+        case 2: inv_band_launch<NS_, false, int16_t, false>(ta, xa, st); break; \
+        default: inv_band_launch<NS_, false, int16_t, true>(ta, xa, st); break; \
+        }
+        if (ls.n == 4) { ALICE_INV(4) } else { ALICE_INV(2) }
+#undef ALICE_INV
     }
-    if (bp.slots == 1) flush(st);
-    return true;
-}
-
-bool launch_inverse_transform(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const int32_t step[3],
-                              bool exact, bool mid16, bool lds16, void* d_scratch, uint8_t* d_rgb, hipStream_t st) {
-    InversePipe p;
-    if (!p.enqueue(d_sym, d, wavelet, step, exact, mid16, lds16, d_scratch, d_rgb, st)) return false;
-    p.flush(st);
     return true;
 }
 

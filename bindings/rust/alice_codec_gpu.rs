@@ -15,9 +15,11 @@
 //!   FastQuantizer::{new, with_dead_zone, quantize, dequantize, quantize_buffer, dequantize_buffer,
 //!                   quantize_buffer_simd, step, dead_zone}   src/quant.rs:190-347
 //!   to_symbols / from_symbols / build_histogram        src/quant.rs:547, 572, 594
-//!   FrequencyTable::{from_histogram, uniform, get_symbol, len, is_empty}   src/rans.rs:102, 158, 194, 209, 216
-//!   RansEncoder::{new, with_capacity, encode_symbols, finish}               src/rans.rs:249, 258, 288, 298
-//!   RansDecoder::{new, decode_n}                       src/rans.rs:330, 375
+//!   FrequencyTable::{from_histogram, uniform, get_symbol, len, is_empty}   src/rans.rs:102, 158, 194, 209, 216 (any n <= 256)
+//!   RansEncoder::{new, with_capacity, encode, encode_symbols, finish}       src/rans.rs:249, 258, 269, 288, 298
+//!   RansDecoder::{new, decode, decode_n, is_empty}     src/rans.rs:330, 351, 375, 385
+//!   quantize_subband / dequantize_subband              src/quant.rs:518, 531
+//!   encode_many / decode_many (chunk driver, optionally over several GPUs)   src/pipeline.rs:461-497
 //!
 //! Every call computes on the GPU; without an MI355X the library returns an error (`CodecError::Device`), it never
 //! falls back to the CPU.  Results are byte-identical to the reference's (this repository's parity tests), with one
@@ -34,6 +36,8 @@ use std::os::raw::{c_char, c_int};
 #[repr(C)] pub struct RawEncoder { _p: [u8; 0] }
 #[repr(C)] pub struct RawChunk { _p: [u8; 0] }
 #[repr(C)] pub struct RawFastQuantizer { _p: [u8; 0] }
+#[repr(C)] pub struct RawRansEncoder { _p: [u8; 0] }
+#[repr(C)] pub struct RawRansDecoder { _p: [u8; 0] }
 
 #[link(name = "alice_codec")]
 extern "C" {
@@ -69,8 +73,26 @@ extern "C" {
     fn alice_codec_from_symbols(symbols: *const u8, n: u64, coeffs: *mut i32, n_out: u64) -> c_int;
     fn alice_codec_build_histogram(symbols: *const u8, n: u64, hist: *mut u32) -> c_int;
     fn alice_codec_freq_table_from_histogram(hist: *const u32, cum_freq: *mut u16, freq: *mut u16) -> c_int;
+    fn alice_codec_freq_table_from_histogram_n(hist: *const u32, n_symbols: u32, cum_freq: *mut u16, freq: *mut u16) -> c_int;
     fn alice_codec_rans_encode(symbols: *const u8, n: u64, cum_freq: *const u16, freq: *const u16, out_len: *mut u64) -> *mut u8;
     fn alice_codec_rans_decode(bytes: *const u8, len: u64, cum_freq: *const u16, freq: *const u16, n: u64, symbols: *mut u8) -> c_int;
+    fn alice_codec_rans_encoder_new() -> *mut RawRansEncoder;
+    fn alice_codec_rans_encoder_destroy(e: *mut RawRansEncoder);
+    fn alice_codec_rans_encoder_encode(e: *mut RawRansEncoder, cum_freq: u16, freq: u16) -> c_int;
+    fn alice_codec_rans_encoder_encode_symbols(e: *mut RawRansEncoder, symbols: *const u8, n: u64, cum_freq: *const u16, freq: *const u16) -> c_int;
+    fn alice_codec_rans_encoder_finish(e: *mut RawRansEncoder, out_len: *mut u64) -> *mut u8;
+    fn alice_codec_rans_decoder_new(data: *const u8, len: u64) -> *mut RawRansDecoder;
+    fn alice_codec_rans_decoder_destroy(d: *mut RawRansDecoder);
+    fn alice_codec_rans_decoder_decode_n(d: *mut RawRansDecoder, n: u64, cum_freq: *const u16, freq: *const u16, symbols: *mut u8) -> c_int;
+    fn alice_codec_rans_decoder_is_empty(d: *const RawRansDecoder) -> c_int;
+    fn alice_codec_quantize_subband(step: i32, dead_zone: i32, coeffs: *const i32, n: u64, out: *mut i32, n_out: u64) -> c_int;
+    fn alice_codec_dequantize_subband(step: i32, coeffs: *const i32, n: u64, out: *mut i32, n_out: u64) -> c_int;
+    fn alice_codec_encode_many(e: *const RawEncoder, rgb: *const u8, rgb_len: u64, w: u32, h: u32, f: u32, n_chunks: u32, out: *mut *mut RawChunk) -> c_int;
+    fn alice_codec_decode_many(chunks: *const *const RawChunk, n_chunks: u32, rgb_out: *mut u8, rgb_out_len: u64) -> c_int;
+    fn alice_codec_encode_many_devices(e: *const RawEncoder, rgb: *const u8, rgb_len: u64, w: u32, h: u32, f: u32, n_chunks: u32,
+                                       devices: *const c_int, n_devices: u32, out: *mut *mut RawChunk) -> c_int;
+    fn alice_codec_decode_many_devices(chunks: *const *const RawChunk, n_chunks: u32, devices: *const c_int, n_devices: u32,
+                                       rgb_out: *mut u8, rgb_out_len: u64) -> c_int;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -105,6 +127,11 @@ fn last_error(expected: usize, got: usize, width: u32, height: u32, step: i32) -
         6 => CodecError::ReferenceDiverges,
         _ => CodecError::Device(msg),
     }
+}
+
+/// 0 -> Ok, anything else -> the calling thread's last error (expected / got fill InvalidBufferSize)
+fn check(rc: c_int, expected: usize, got: usize) -> Result<(), CodecError> {
+    if rc == 0 { Ok(()) } else { Err(last_error(expected, got, 0, 0, 0)) }
 }
 
 unsafe fn take(p: *mut u8, n: u64) -> Vec<u8> {
@@ -322,63 +349,113 @@ pub fn build_histogram(symbols: &[u8]) -> [u32; 256] {
 pub struct RansSymbol { pub cum_freq: u16, pub freq: u16 }
 impl RansSymbol { pub const fn new(cum_freq: u16, freq: u16) -> Self { Self { cum_freq, freq } } }   // :69
 
-/// src/rans.rs:85, over the pipeline's 256-symbol alphabet
-pub struct FrequencyTable { cum_freq: [u16; 256], freq: [u16; 256] }
+/// src/rans.rs:85.  n symbols, 1 <= n <= 256 (the coders address symbols as u8); the arrays always hold 256 entries,
+/// those from n on are (0, 0).
+pub struct FrequencyTable { cum_freq: [u16; 256], freq: [u16; 256], n_symbols: usize }
 impl FrequencyTable {
-    /// src/rans.rs:102 (freq 1 for unused symbols, wrapping fix on the last symbol, uniform fallback when empty)
+    /// src/rans.rs:102 (freq 1 for unused symbols, wrapping fix on the last symbol, uniform fallback when empty); any
+    /// slice length the u8 symbol API can address.  Panics where the reference panics (an empty slice divides by zero in
+    /// `uniform(0)`, :159) and for more than 256 symbols, which the GPU path does not carry.
     pub fn from_histogram(histogram: &[u32]) -> Self {
-        assert!(histogram.len() == 256, "the GPU path carries the pipeline's 256-bin histograms");
-        let mut t = Self { cum_freq: [0; 256], freq: [0; 256] };
-        unsafe { alice_codec_freq_table_from_histogram(histogram.as_ptr(), t.cum_freq.as_mut_ptr(), t.freq.as_mut_ptr()); }
+        let mut t = Self { cum_freq: [0; 256], freq: [0; 256], n_symbols: histogram.len() };
+        let rc = unsafe { alice_codec_freq_table_from_histogram_n(histogram.as_ptr(), histogram.len() as u32, t.cum_freq.as_mut_ptr(), t.freq.as_mut_ptr()) };
+        assert!(rc == 0, "FrequencyTable::from_histogram: {:?}", last_error(0, 0, 0, 0, 0));
         t
     }
     /// src/rans.rs:158
-    pub fn uniform(n_symbols: usize) -> Self {
-        assert!(n_symbols == 256);
-        Self::from_histogram(&[0u32; 256])   // total == 0 -> uniform (:106-109)
+    pub fn uniform(n_symbols: usize) -> Self { Self::from_histogram(&vec![0u32; n_symbols]) }   // total == 0 -> uniform(n) (:106-109)
+    pub fn get_symbol(&self, sym: u8) -> RansSymbol {                                             // :194 (panics out of range, as the Vec index does)
+        assert!((sym as usize) < self.n_symbols);
+        RansSymbol::new(self.cum_freq[sym as usize], self.freq[sym as usize])
     }
-    pub fn get_symbol(&self, sym: u8) -> RansSymbol { RansSymbol::new(self.cum_freq[sym as usize], self.freq[sym as usize]) }   // :194
-    pub const fn len(&self) -> usize { 256 }          // :209
-    pub const fn is_empty(&self) -> bool { false }    // :216
+    pub const fn len(&self) -> usize { self.n_symbols }          // :209
+    pub const fn is_empty(&self) -> bool { self.n_symbols == 0 } // :216
 }
 
-/// src/rans.rs:238.  The reference consumes symbols last-to-first inside `encode_symbols` and reverses the whole byte
-/// vector in `finish`; the chain kernel needs all symbols of the stream at once, so they are collected and the device
-/// runs when `finish` is called.  The per-symbol `encode(&RansSymbol)` (:269: the caller feeds (cum, freq) pairs in
-/// reverse order) has no table to hand to the device and is the one method of the reference type not offered here;
-/// `finish` returns a Result because of the one documented divergence (a frequency-0 symbol, :275-283).
-pub struct RansEncoder { symbols: Vec<u8>, table: Option<([u16; 256], [u16; 256])> }
+/// src/rans.rs:238: an encoder object that lives across calls.  Every call runs one chain on the device from the object's
+/// current state (`encode_symbols` s1 then s2 leaves the stream of one call on s2 || s1, :288-294; `encode` takes the
+/// (cum_freq, freq) pair itself, :269-285); the bytes a call emits come back to the host, `finish` prepends the state.
+/// The methods return Results because of the one documented divergence (a frequency-0 symbol, :275-283: the reference
+/// never returns).
+pub struct RansEncoder { raw: *mut RawRansEncoder }
 impl RansEncoder {
-    pub const fn new() -> Self { Self { symbols: Vec::new(), table: None } }                    // :249
-    pub fn with_capacity(capacity: usize) -> Self { Self { symbols: Vec::with_capacity(capacity), table: None } }   // :258
+    pub fn new() -> Self { Self { raw: unsafe { alice_codec_rans_encoder_new() } } }             // :249
+    pub fn with_capacity(_capacity: usize) -> Self { Self::new() }                               // :258 (a hint there too)
+    /// src/rans.rs:269
+    pub fn encode(&mut self, sym: &RansSymbol) -> Result<(), CodecError> {
+        check(unsafe { alice_codec_rans_encoder_encode(self.raw, sym.cum_freq, sym.freq) }, 0, 0)
+    }
     /// src/rans.rs:288
-    pub fn encode_symbols(&mut self, symbols: &[u8], table: &FrequencyTable) {
-        assert!(self.symbols.is_empty(), "one encode_symbols call per stream on the GPU path");
-        self.symbols.extend_from_slice(symbols);
-        self.table = Some((table.cum_freq, table.freq));
+    pub fn encode_symbols(&mut self, symbols: &[u8], table: &FrequencyTable) -> Result<(), CodecError> {
+        if symbols.is_empty() { return Ok(()); }
+        check(unsafe { alice_codec_rans_encoder_encode_symbols(self.raw, symbols.as_ptr(), symbols.len() as u64, table.cum_freq.as_ptr(), table.freq.as_ptr()) }, 0, 0)
     }
     /// src/rans.rs:298: the stream starts with the final state, big-endian
     pub fn finish(mut self) -> Result<Vec<u8>, CodecError> {
-        let (cum, freq) = self.table.take().unwrap_or(([0; 256], [16; 256]));
         let mut n = 0u64;
+        let raw = std::mem::replace(&mut self.raw, std::ptr::null_mut());
         unsafe {
-            let p = alice_codec_rans_encode(self.symbols.as_ptr(), self.symbols.len() as u64, cum.as_ptr(), freq.as_ptr(), &mut n);
+            let p = alice_codec_rans_encoder_finish(raw, &mut n);   // consumes the handle
             if p.is_null() { Err(last_error(0, 0, 0, 0, 0)) } else { Ok(take(p, n)) }
         }
     }
 }
+impl Drop for RansEncoder { fn drop(&mut self) { if !self.raw.is_null() { unsafe { alice_codec_rans_encoder_destroy(self.raw) } } } }
 impl Default for RansEncoder { fn default() -> Self { Self::new() } }
 
-/// src/rans.rs:321
-pub struct RansDecoder<'a> { input: &'a [u8] }
+/// src/rans.rs:321: a decoder object; `decode` / `decode_n` continue from the current state and position (the library
+/// keeps a copy of the input, so the lifetime parameter of the reference type only documents the borrow)
+pub struct RansDecoder<'a> { raw: *mut RawRansDecoder, _input: std::marker::PhantomData<&'a [u8]> }
 impl<'a> RansDecoder<'a> {
-    pub fn new(input: &'a [u8]) -> Self { Self { input } }   // :330
+    pub fn new(input: &'a [u8]) -> Self {   // :330
+        Self { raw: unsafe { alice_codec_rans_decoder_new(input.as_ptr(), input.len() as u64) }, _input: std::marker::PhantomData }
+    }
+    /// src/rans.rs:351
+    pub fn decode(&mut self, table: &FrequencyTable) -> u8 { self.decode_n(1, table)[0] }
     /// src/rans.rs:375, including the behaviour on short, truncated and desynchronised streams (:341-347, 365-368)
     pub fn decode_n(&mut self, n: usize, table: &FrequencyTable) -> Vec<u8> {
         let mut out = vec![0u8; n];
-        unsafe {
-            alice_codec_rans_decode(self.input.as_ptr(), self.input.len() as u64, table.cum_freq.as_ptr(), table.freq.as_ptr(), n as u64, out.as_mut_ptr());
-        }
+        unsafe { alice_codec_rans_decoder_decode_n(self.raw, n as u64, table.cum_freq.as_ptr(), table.freq.as_ptr(), out.as_mut_ptr()); }
         out
     }
+    /// src/rans.rs:385
+    pub fn is_empty(&self) -> bool { unsafe { alice_codec_rans_decoder_is_empty(self.raw) != 0 } }
+}
+impl<'a> Drop for RansDecoder<'a> { fn drop(&mut self) { unsafe { alice_codec_rans_decoder_destroy(self.raw) } } }
+
+/// src/quant.rs:518 / :531: a sub-band's coefficients through a Quantizer (step, dead zone)
+pub fn quantize_subband(coeffs: &[i32], step: i32, dead_zone: i32, output: &mut [i32]) -> Result<(), CodecError> {
+    check(unsafe { alice_codec_quantize_subband(step, dead_zone, coeffs.as_ptr(), coeffs.len() as u64, output.as_mut_ptr(), output.len() as u64) }, coeffs.len(), output.len())
+}
+pub fn dequantize_subband(coeffs: &[i32], step: i32, output: &mut [i32]) -> Result<(), CodecError> {
+    check(unsafe { alice_codec_dequantize_subband(step, coeffs.as_ptr(), coeffs.len() as u64, output.as_mut_ptr(), output.len() as u64) }, coeffs.len(), output.len())
+}
+
+/// The chunk driver over several GPUs of the node (src/pipeline.rs:461-497: 64-frame chunks are independent): chunk k
+/// runs on devices[k % devices.len()], one host thread per entry inside the library; an empty list = the calling
+/// thread's device.  Byte-identical to `chunks.len()` calls of `FrameEncoder::encode`.
+pub fn encode_many(encoder: &FrameEncoder, rgb_chunks: &[u8], width: u32, height: u32, frames: u32, n_chunks: u32, devices: &[i32])
+                   -> Result<Vec<EncodedChunk>, CodecError> {
+    let raw_enc = unsafe { alice_codec_encoder_create_ex(encoder.quality, encoder.wavelet_type as u8) };
+    let mut raw: Vec<*mut RawChunk> = vec![std::ptr::null_mut(); n_chunks as usize];
+    let rc = unsafe {
+        if devices.is_empty() { alice_codec_encode_many(raw_enc, rgb_chunks.as_ptr(), rgb_chunks.len() as u64, width, height, frames, n_chunks, raw.as_mut_ptr()) }
+        else { alice_codec_encode_many_devices(raw_enc, rgb_chunks.as_ptr(), rgb_chunks.len() as u64, width, height, frames, n_chunks,
+                                               devices.as_ptr(), devices.len() as u32, raw.as_mut_ptr()) }
+    };
+    unsafe { alice_codec_encoder_destroy(raw_enc) };
+    check(rc, 0, 0)?;
+    Ok(raw.into_iter().map(|r| EncodedChunk { raw: r }).collect())
+}
+pub fn decode_many(chunks: &[EncodedChunk], devices: &[i32]) -> Result<Vec<u8>, CodecError> {
+    if chunks.is_empty() { return Ok(Vec::new()); }
+    let raw: Vec<*const RawChunk> = chunks.iter().map(|c| c.raw as *const RawChunk).collect();
+    let per = chunks[0].width() as usize * chunks[0].height() as usize * chunks[0].frames() as usize * 3;
+    let mut out = vec![0u8; per * chunks.len()];
+    let rc = unsafe {
+        if devices.is_empty() { alice_codec_decode_many(raw.as_ptr(), raw.len() as u32, out.as_mut_ptr(), out.len() as u64) }
+        else { alice_codec_decode_many_devices(raw.as_ptr(), raw.len() as u32, devices.as_ptr(), devices.len() as u32, out.as_mut_ptr(), out.len() as u64) }
+    };
+    check(rc, 0, 0)?;
+    Ok(out)
 }

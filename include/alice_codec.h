@@ -160,6 +160,11 @@ int alice_codec_batch_decode_finish(AliceBatch *batch);
 int alice_codec_batch_stage_ms(const AliceBatch *batch, float out[6]);
 /* device pointer to the batch's u8 symbols (3 * padded per chunk, channel-major) -- for parity tests */
 const void *alice_codec_batch_symbols_ptr(const AliceBatch *batch);
+/* Device memory the batch holds per chunk (symbols = decoded pixels, the .alc buffer at its current capacities, tables)
+ * and independent of the chunk count (transform scratch): a trial batch of one chunk tells how many chunks the free HBM
+ * holds. */
+uint64_t alice_codec_batch_bytes_per_chunk(const AliceBatch *batch);
+uint64_t alice_codec_batch_fixed_bytes(const AliceBatch *batch);
 uint64_t alice_codec_batch_padded_pixels(const AliceBatch *batch);
 
 /* ---- stage level (host pointers; data is staged through the GPU) ---- */

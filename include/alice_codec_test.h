@@ -31,11 +31,10 @@ int alice_codec_test_transform_ms(const void *d_rgb, void *d_sym, void *d_rgb_ou
                                   uint32_t height, uint32_t frames, uint8_t wavelet_type, uint8_t quality, uint32_t n_chunks,
                                   uint32_t reps, int probe, float out_ms[2], void *hip_stream);
 
-/* Band plan of the transform launches (csrc/transform.hip), process-wide, negative = keep: target size of a band slot in
- * KiB (0 = never cut a chunk into bands; default 65536), cap on the temporal role's workgroups per launch (0 = none),
- * 1 = every role in a launch of its own instead of two roles per launch.  The suite uses it to run small shapes through
+/* Band plan of the transform launches (csrc/transform.hip, "Bands"), process-wide: target size of a band slot in KiB
+ * (0 = never cut a chunk into bands; negative = keep; default 1048576).  The suite uses it to run small shapes through
  * many bands; results never depend on it. */
-void alice_codec_test_set_tuning(long band_kb, long t_blocks, long no_fuse);
+void alice_codec_test_set_tuning(long band_kb);
 
 /* Resident chain kernels: what the runtime reports for the one-chain-per-SIMD instances of the rANS kernels.
  * out[0..2] = encoder: registers per lane (VGPR + AGPR, as allocated), static LDS bytes, workgroups per CU the runtime

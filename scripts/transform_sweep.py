@@ -1,7 +1,7 @@
 """Developer sweep on a GPU box: milliseconds per 1920x1080x64 chunk of the forward and inverse transform launches alone
-(alice_codec_test_transform_ms: HIP events around the same pipes a batch uses, chains excluded) over the band plan's
-tuning -- slot target, cap on the temporal role's workgroups, roles fused or in launches of their own -- and the
-VALU-floor twins of the kernels (global loads and stores replaced by register moves).  Writes one JSON file.
+(alice_codec_test_transform_ms: HIP events around the launches a batch uses, chains excluded) over the band plan's
+target and the probe twins of the kernels (global loads and / or stores replaced by register moves: the VALU floor and
+what each kind of access costs on top of it).  Writes one JSON file.
 
     python scripts/transform_sweep.py out.json [wavelet 0|1|2] [quality] [quick]"""
 import ctypes as C
@@ -31,34 +31,27 @@ ms = (C.c_float * 2)()
 rows = []
 
 
-def run(band_kb, t_blocks, no_fuse, probe=0):
-    lib.alice_codec_test_set_tuning(band_kb, t_blocks, no_fuse)
+def run(band_kb, probe=0):
+    lib.alice_codec_test_set_tuning(band_kb)
     rc = lib.alice_codec_test_transform_ms(rgb.data_ptr(), sym.data_ptr(), out.data_ptr(), NB, W, H, F, k, q, NCH, REPS, probe, ms, st)
     assert rc == 0, rc
-    r = {"band_kb": band_kb, "t_blocks": t_blocks, "no_fuse": no_fuse, "probe": probe,
-         "forward_ms": round(ms[0], 4), "inverse_ms": round(ms[1], 4),
+    r = {"band_kb": band_kb, "probe": probe, "forward_ms": round(ms[0], 4), "inverse_ms": round(ms[1], 4),
          "forward_frac_of_8TBs": round(6 * px / (ms[0] * 1e-3) / 8e12, 4), "inverse_frac_of_8TBs": round(6 * px / (ms[1] * 1e-3) / 8e12, 4)}
     rows.append(r)
     print(r, flush=True)
     return r
 
 
-run(0, 0, 1)      # warm-up of every instance
-run(65536, 512, 0)
+run(0)            # warm-up of every instance
 rows.clear()
-base = run(0, 0, 1)                      # round-2 structure: uncut, one role per launch
-run(0, 0, 1, probe=1)                    # its VALU floor: loads and stores replaced by register moves
-run(0, 0, 1, probe=2)                    # only the loads replaced
-run(0, 0, 1, probe=3)                    # only the stores replaced
-bands = (65536,) if quick else (24576, 32768, 65536, 98304, 131072, 200000)
-tbs = (512,) if quick else (0, 128, 256, 512, 1024)
-for band in bands:
-    for tb in tbs:
-        run(band, tb, 0)
-    run(band, 0, 1)                      # banded, roles in launches of their own
-best = min((r for r in rows if not r["probe"]), key=lambda r: r["forward_ms"] + r["inverse_ms"])
-run(best["band_kb"], best["t_blocks"], best["no_fuse"], probe=1)
-lib.alice_codec_test_set_tuning(64 * 1024, 512, 0)
+base = run(0)                            # the uncut chunk: one tile launch and one temporal launch per direction
+run(0, probe=1)                          # its VALU floor: loads and stores replaced by register moves
+run(0, probe=2)                          # only the loads replaced
+run(0, probe=3)                          # only the stores replaced
+for band in (() if quick else (32768, 65536, 131072, 262144, 409600)):
+    run(band)
+lib.alice_codec_test_set_tuning(1024 * 1024)
 json.dump({"chunk": f"{W}x{H}x{F}", "wavelet": k, "quality": q, "chunks_per_pass": NCH, "passes": REPS, "distinct_buffers": NB,
-           "algorithmic_bytes_per_chunk": 6 * px, "rows": rows, "best": best, "uncut_unfused": base}, open(out_path, "w"), indent=1)
-print("best", best)
+           "algorithmic_bytes_per_chunk": 6 * px, "rows": rows, "uncut": base,
+           "probe_modes": {"1": "loads and stores replaced by register moves (VALU floor)", "2": "loads replaced", "3": "stores replaced"}},
+          open(out_path, "w"), indent=1)
