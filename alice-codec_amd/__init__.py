@@ -19,6 +19,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# Kernels of HIP streams that share a hardware queue run one after the other, the runtime creates 4 queues by default, and
+# a chain kernel runs for seconds: host threads calling encode / decode concurrently need more (csrc/codec.hip,
+# widen_hw_queues_once).  The library asks for 8 itself, but in a Python process torch usually initialises HIP first -- so
+# ask here, at import, before anything has touched the device.  An existing setting is kept.
+if not os.environ.get("ALICE_CODEC_KEEP_HW_QUEUES"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # ALICE_CODEC_LIB: developer override (A/B runs of two builds of the library); the product loads the in-tree build
 LIB_PATH = os.environ.get("ALICE_CODEC_LIB") or os.path.join(_HERE, "libalice_codec.so")
 
@@ -171,6 +178,8 @@ def load_library() -> C.CDLL:
         "alice_codec_batch_symbols_ptr": (vp, [vp]),
         "alice_codec_batch_rgb_ptr": (vp, [vp, C.c_uint32]),
         "alice_codec_batch_padded_pixels": (C.c_uint64, [vp]),
+        "alice_codec_batch_bytes_per_chunk": (C.c_uint64, [vp]),
+        "alice_codec_batch_fixed_bytes": (C.c_uint64, [vp]),
         "alice_codec_wavelet2d_forward": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64]),
         "alice_codec_wavelet2d_inverse": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64]),
         "alice_codec_wavelet3d_forward": (C.c_int, [C.c_uint8, _i32p, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -956,3 +965,13 @@ class Batch:
     @property
     def padded_pixels(self) -> int:
         return load_library().alice_codec_batch_padded_pixels(self._h)
+
+    @property
+    def bytes_per_chunk(self) -> int:
+        """device bytes the batch holds per chunk at its current .alc capacities (symbols, .alc buffer, tables)"""
+        return load_library().alice_codec_batch_bytes_per_chunk(self._h)
+
+    @property
+    def fixed_bytes(self) -> int:
+        """device bytes the batch holds whatever its chunk count (transform scratch)"""
+        return load_library().alice_codec_batch_fixed_bytes(self._h)

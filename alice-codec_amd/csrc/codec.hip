@@ -68,7 +68,21 @@ thread_local int tl_stream_device = -1;
 // go back to the pool (an error return may leave kernels in flight on them)
 thread_local hipStream_t tl_scope_stream = nullptr;
 
+// HIP maps streams onto hardware queues, 4 by default, and kernels of streams that share a queue run one after the other.
+// A chain kernel runs for seconds, so with the default only four host threads' calls make progress at a time (measured:
+// 64 threads through alice_codec_encode64 ran 4 chunks at a time).  Ask for more before the runtime creates its queues --
+// 8 is what the device honours (32 behaved like 8); a host that has initialised HIP already, or set the variable itself,
+// keeps what it has.  ALICE_CODEC_KEEP_HW_QUEUES=1 leaves the environment alone.
+void widen_hw_queues_once() {
+    static const bool done = [] {
+        if (!getenv("ALICE_CODEC_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        return true;
+    }();
+    (void)done;
+}
+
 int ensure_device() {
+    widen_hw_queues_once();
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -95,7 +109,10 @@ int get_stream(hipStream_t* out) {
     return kOk;
 }
 
-// Size-bucketed cache of device allocations (hipMalloc/hipFree are synchronising and slow).
+// Size-bucketed cache of device allocations.  hipFree waits for EVERY kernel running on the device -- with other threads'
+// chains in flight that is seconds (64 host threads through alice_codec_encode64 took 49 s instead of 6 while the cache
+// was capped at 8 GB and every call's buffers were freed behind it) -- so blocks are kept up to half of the device's
+// memory and given back only by alice_codec_trim() or when an allocation fails.
 class DevicePool {
 public:
     int alloc(size_t bytes, void** out) {
@@ -129,7 +146,8 @@ public:
         if (!p) return;
         const size_t b = bucket(bytes);
         std::lock_guard<std::mutex> g(mu_);
-        if (cached_ + b > kMaxCached) { (void)hipFree(p); return; }
+        // (very large blocks -- a batch's symbol volume -- only ever fit the batch that made them: not worth keeping)
+        if (b > (size_t(8) << 30) || cached_ + b > max_cached()) { (void)hipFree(p); return; }
         free_[{dev, b}].push_back(p);
         cached_ += b;
     }
@@ -150,7 +168,15 @@ private:
         const size_t g = size_t(2) << 20;  // 2 MiB granules
         return (bytes + g - 1) / g * g;
     }
-    static constexpr size_t kMaxCached = size_t(8) << 30;
+    // half of the device's memory (of the first device asked about: the devices of a node are alike), at least 8 GB
+    static size_t max_cached() {
+        static const size_t cap = [] {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return size_t(8) << 30; }
+            return std::max(total_b / 2, size_t(8) << 30);
+        }();
+        return cap;
+    }
     std::mutex mu_;
     std::map<std::pair<int, size_t>, std::vector<void*>> free_;
     size_t cached_ = 0;
@@ -951,6 +977,7 @@ char* alice_codec_version(void) {
 int alice_codec_last_error(void) { return tl_err; }
 const char* alice_codec_last_error_message(void) { return tl_msg.c_str(); }
 int alice_codec_device_count(void) {
+    widen_hw_queues_once();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;

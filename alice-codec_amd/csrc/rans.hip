@@ -25,6 +25,8 @@
 // low bytes of the pre-renormalisation state) is then a wave-parallel ballot/popcount
 // compaction.  Bytes are written back to front so the stream comes out already
 // "reversed" as RansEncoder::finish leaves it.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -191,6 +193,26 @@ __global__ __launch_bounds__(256) void rans_table_from_arrays_kernel(const uint1
     if (s == 0) table->flags = flags_sh;
 }
 
+// Two chains on one SIMD (more than 1024 chains in flight): the SIMD's issue arbiter prefers the OLDER wave, so the older
+// chain runs almost undisturbed and the younger one gets what is left -- and the step waits for the slowest chain.  Taking
+// turns was the proposed cure (round 2): every wave derives its priority from a bit of the shader clock
+// (the same for both waves of a SIMD) XOR the low bit of its wave slot (consecutive slots: different for the two),
+// re-evaluated once per tile, so at any time one of the two has priority 1 and the other 0.  Waves never wait on each
+// other: this is arbitration only.  MEASURED in round 3 (960x540x64 chunks, profiles/r03_chain_probe_960x540_turns_*.log):
+//   1200 chains (176 SIMDs shared): the slowest encoder of a pair 61.0 instead of 63.5 cycles/symbol (kernel 25.6 instead of
+//   26.6 ns/symbol), decoders 48.6 instead of 49.3 ns/symbol -- the pairs move closer but do not finish together;
+//   2046 chains (every SIMD shared): encoders unchanged (38.0 ns/symbol), decoders 86.4 instead of 79.2 ns/symbol: WORSE.
+// And two chains per SIMD buy little in the first place: 2046 chains encode 53.9 Gsym/s against 50.3 with 1023 (+7 %) and
+// decode 25.8 against 26.4 (-2 %): eight decoders on a CU saturate its one scalar unit.  So it is OFF unless
+// ALICE_CHAIN_TURNS=1, and one chain per SIMD stays the operating point.  kExclusive instances never evaluate it.
+__device__ __forceinline__ void chain_take_turns(uint32_t enabled) {
+    if (!enabled) return;
+    const uint32_t turn = (uint32_t)(clock64() >> 17);                                   // ~55 us at 2.4 GHz
+    const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);           // HW_REG_HW_ID[3:0]: wave slot on the SIMD
+    if ((turn ^ slot) & 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // ----------------------------------------------------------------------------------
 // Encode chain
 // ----------------------------------------------------------------------------------
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                                                          unsigned n_split,
                                                          RansResult* __restrict__ results,
                                                          unsigned long long cap1, unsigned long long cap2,
-                                                         uint32_t x_init, uint32_t keep_open) {
+                                                         uint32_t x_init, uint32_t keep_open, uint32_t take_turns) {
     __shared__ uint4 tab_a[256];  // xmax, xmax8, rcp, rsh
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
     __shared__ __attribute__((aligned(16))) uint8_t tile[kEncTile];
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
 
     uint4 cur = load_tile(0);
     for (unsigned long long j = 0; j < ntiles; ++j) {
+        if (!kExclusive && (j & 7ull) == 0ull) chain_take_turns(take_turns);
         __syncthreads();
         ((uint4*)tile)[lane] = cur;
         __syncthreads();
@@ -550,7 +573,7 @@ __device__ __forceinline__ void dec_tile_dry(uint32_t& x, const RansDecSlots* sl
 // four (up to 1024 chains: one per SIMD) or seven chains share a CU.
 template <bool kExclusive>
 __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* __restrict__ descs,
-                                                         RansResult* __restrict__ results) {
+                                                         RansResult* __restrict__ results, uint32_t take_turns) {
     if constexpr (kExclusive) asm volatile("" ::: "a63");   // 226 VGPRs + 64 AGPRs > 256: one chain per SIMD
     __shared__ __attribute__((aligned(16))) uint8_t c2s[kProbScale];                  // cum_to_sym
     __shared__ uint32_t symtab[256];                                                    // freq | cum << 16 (exact loop)
@@ -594,6 +617,7 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
     uint32_t n_fast = 0u, n_slow = 0u, paths = 0u;
 
     while (done < d.n) {
+        if (!kExclusive) chain_take_turns(take_turns);
         const unsigned long long remain = d.n - done;
         const uint32_t want = remain < (unsigned long long)kDecTile ? (uint32_t)remain : (uint32_t)kDecTile;
         // A frequency-4096 entry is wrong for x = 0 only (build_dec_slots), and x = 0 looks up slot 0: the dry tile is
@@ -779,6 +803,12 @@ void launch_rans_table_from_arrays(const uint16_t* d_cum, const uint16_t* d_freq
 // than half of a SIMD's register file, which leaves the dispatcher no choice but one chain per SIMD.  Beyond that two
 // chains per SIMD are wanted (together they run at about 1.5x the rate of one); dynamic LDS that the kernels never touch
 // then caps the workgroups per CU at 8 so that the surplus spreads over all CUs.
+// ALICE_CHAIN_TURNS=1 switches the priority alternation of shared SIMDs on (developer A/B, scripts/chain_probe.py)
+static uint32_t chain_turns_enabled() {
+    static const uint32_t on = [] { const char* v = getenv("ALICE_CHAIN_TURNS"); return (v && *v == '1') ? 1u : 0u; }();
+    return on;
+}
+
 static unsigned chain_lds_pad(int n_chains, unsigned static_lds) {
     if (n_chains <= 1024 || n_chains > 2048) return 0u;
     const unsigned want = 163840u / 8u - 1024u;   // a ninth workgroup no longer fits (160 KB of LDS per CU)
@@ -830,14 +860,15 @@ void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, c
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
                        (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, n_split,
                        d_results, (unsigned long long)(cap_co ? cap_co : cap), (unsigned long long)(cap_cg ? cap_cg : cap),
-                       x_init, keep_open ? 1u : 0u);
+                       x_init, keep_open ? 1u : 0u, chain_turns_enabled());
 }
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {
     if (n_chains <= 0) return;
     auto kern = n_chains <= 1024 ? rans_decode_kernel<true> : rans_decode_kernel<false>;
     const ChainKernelFacts& facts = chain_kernel_facts();
-    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, facts.ok ? facts.dec_lds_plain : 21776u + 256u), st, d_descs, d_results);
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, facts.ok ? facts.dec_lds_plain : 21776u + 256u), st, d_descs, d_results,
+                       chain_turns_enabled());
 }
 
 }  // namespace alice

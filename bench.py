@@ -135,6 +135,61 @@ def verify_and_baseline(first, last, frames: int) -> dict:
     }
 
 
+def host_api_measure(threads=(1, 8, 64), wavelet=None, quality=None) -> dict:
+    """The drop-in path as a reference caller would use it (the handles are Send + Sync, src/pipeline.rs:635-644, so
+    the natural move is a thread pool over chunks): T host threads share one FrameEncoder and one FrameDecoder, each
+    calls alice_codec_encode64 / alice_codec_decode64 on its OWN 1920x1080x64 chunk held in pageable host memory --
+    host -> device copy, transforms, the chunk's three serial chains, device -> host copy, all inside the call.
+    Aggregate Mpix/s per phase (all threads encode, then all decode), PCIe included.  Never part of `value`."""
+    _mods()
+    import threading
+    wavelet = WAVELET if wavelet is None else wavelet
+    quality = QUALITY if quality is None else quality
+    dev = torch.device("cuda", torch.cuda.current_device())
+    enc = ac.FrameEncoder.with_wavelet(quality, wavelet)
+    dec = ac.FrameDecoder()
+    px = W * H * F
+    tmax = max(threads)
+    host = [synth_chunk(dev, 5000 + i).reshape(-1).cpu().numpy() for i in range(tmax)]   # pageable
+    torch.cuda.empty_cache()
+    rows = []
+    warm = enc.encode(host[0], W, H, F)       # library load, pool, code objects
+    dec.decode(warm)
+    del warm
+    for T in threads:
+        chunks, outs = [None] * T, [None] * T
+        gate = threading.Barrier(T + 1)
+
+        def run(fn):
+            def body(i):
+                ac.set_device(dev.index or 0)
+                gate.wait()
+                fn(i)
+            th = [threading.Thread(target=body, args=(i,)) for i in range(T)]
+            [t.start() for t in th]
+            gate.wait()
+            t0 = time.perf_counter()
+            [t.join() for t in th]
+            return time.perf_counter() - t0
+
+        def do_enc(i): chunks[i] = enc.encode(host[i], W, H, F)
+        def do_dec(i): outs[i] = dec.decode(chunks[i])
+        t_enc = run(do_enc)
+        t_dec = run(do_dec)
+        ok = all(o is not None and o.size == px * 3 for o in outs)
+        rows.append({"threads": T, "encode_s": round(t_enc, 3), "decode_s": round(t_dec, 3),
+                     "encode_mpix_s": round(T * px / t_enc / 1e6, 2), "decode_mpix_s": round(T * px / t_dec / 1e6, 2),
+                     "encode_plus_decode_mpix_s": round(2 * T * px / (t_enc + t_dec) / 1e6, 2), "all_calls_succeeded": bool(ok),
+                     "alc_bytes_chunk0": len(chunks[0].to_bytes())})
+        print(f"[bench] host api, {T} thread(s): encode {rows[-1]['encode_mpix_s']} Mpix/s, decode {rows[-1]['decode_mpix_s']} Mpix/s", file=sys.stderr)
+        del chunks, outs
+        ac.load_library().alice_codec_trim()
+    return {"what": "T host threads, one shared FrameEncoder / FrameDecoder handle, alice_codec_encode64 / alice_codec_decode64 per thread on its own "
+                    f"{W}x{H}x{F} chunk in pageable host memory ({WAVELET.name if wavelet is None else ac.WaveletType(wavelet).name} q={quality}); aggregate rate per phase, "
+                    "PCIe and the three serial chains of every chunk inside the call; not part of `value`",
+            "rows": rows}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,31 +329,33 @@ def main(argv=None) -> None:
     px_chunk = W * H * F
     stream = torch.cuda.current_stream().cuda_stream
     chunk0 = synth_chunk(dev, rank * 1000)
-    # ---- how many chunks: one trial encode of chunk 0 tells the size of a chunk's .alc buffer
+    # ---- how many chunks: a trial batch of one chunk tells what the library holds per chunk (.alc capacities from this
+    # content's histograms) and whatever the count (transform scratch); the inputs add 3 bytes per pixel
     sizing = {}
     if args.chunks == "auto":
         trial = ac.Batch(W, H, F, 1, QUALITY, WAVELET)
         trial.encode(chunk0.data_ptr(), stream)
         trial.encode_finish()
+        per_chunk = px_chunk * 3 + trial.bytes_per_chunk + (px_chunk * 3 if args.separate_output else 0)
+        fixed = trial.fixed_bytes
         alc_stride = trial.alc_stride
         del trial
         ac.load_library().alice_codec_trim()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         free_b, total_b = torch.cuda.mem_get_info(dev)
-        per_chunk = px_chunk * 3 + px_chunk * 3 + alc_stride + 2 * 3 * 47000   # RGB in, symbols (= RGB out), .alc, tables
-        per_chunk += px_chunk * 3 if args.separate_output else 0
-        fixed = px_chunk * 12 + (2 << 30)                                      # one chunk's transform scratch; slack
         if use_dist:
             fixed += 2 * max(world - 1, 1) * alc_stride                        # the root's receive ring
-        B = int((free_b * 0.95 - fixed) // per_chunk)
+        # (the capacities grow a little when another chunk's Y stream is longer than chunk 0's: 0.2 % of the .alc buffers kept back)
+        margin = int(0.002 * 341 * alc_stride) + (64 << 20)
+        B = int((free_b - fixed - margin) // per_chunk)
         B = max(1, min(B, 341))
         if use_dist:
             tb = torch.tensor([B], dtype=torch.int64, device=dev)
             dist.all_reduce(tb, op=dist.ReduceOp.MIN)
             B = int(tb.item())
-        sizing = {"chunks": "auto", "free_hbm_gb_at_start": round(free_b / 1e9, 1), "bytes_per_chunk_in_flight": int(per_chunk),
-                  "alc_buffer_bytes_per_chunk": int(alc_stride)}
+        sizing = {"chunks": "auto", "free_hbm_gb_at_start": round(free_b / 1e9, 2), "bytes_per_chunk_in_flight": int(per_chunk),
+                  "alc_buffer_bytes_per_chunk": int(alc_stride), "fixed_bytes": int(fixed), "margin_bytes": int(margin)}
     else:
         B = int(args.chunks)
         sizing = {"chunks": "fixed on the command line"}
@@ -314,7 +371,26 @@ def main(argv=None) -> None:
     torch.cuda.synchronize()
     torch.cuda.empty_cache()   # the generator's temporaries
     out = torch.empty_like(rgb) if args.separate_output else None
-    batch = ac.Batch(W, H, F, B, QUALITY, WAVELET)
+    # the batch; if the device runs out of memory after all (the first encode allocates the .alc buffers), drop chunks
+    # from the end until it fits: the dropped inputs stay allocated, every chunk less frees its symbols and .alc buffer
+    batch = None
+    dropped = 0
+    while True:
+        try:
+            batch = ac.Batch(W, H, F, B, QUALITY, WAVELET)
+            batch.encode(rgb.data_ptr(), stream)
+            batch.encode_finish()
+            break
+        except ac.CodecError as e:
+            if e.kind != "OutOfMemory" or B <= 1 or use_dist:
+                raise
+            batch = None
+            ac.load_library().alice_codec_trim()
+            torch.cuda.synchronize()
+            B -= 1
+            dropped += 1
+            print(f"[bench] out of device memory with {B + 1} chunks: trying {B}", file=sys.stderr)
+    sizing["chunks_dropped_after_out_of_memory"] = dropped
     stage_acc = {}
     n_acc = 0
     # N > 1: the .alc bytes of every rank stream to rank 0 beside the decode, on a side stream; rank 0 hands each chunk to
@@ -394,6 +470,21 @@ def main(argv=None) -> None:
             tb = torch.tensor([1 if bit_exact else 0], dtype=torch.int64, device=dev)
             dist.all_reduce(tb, op=dist.ReduceOp.MIN)
             bit_exact = bool(tb.item())
+    # ---- the drop-in host calls, measured the way a caller of the reference would use them (rank 0 of a one-GPU run
+    # only; the batch goes first: the calls need the device memory)
+    host_api = None
+    if rank == 0 and world == 1 and not args.no_host_api:
+        chunks_per_gpu_used = B
+        del batch
+        del rgb
+        out = None
+        ac.load_library().alice_codec_trim()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        try:
+            host_api = host_api_measure()
+        except Exception as e:  # noqa: BLE001
+            host_api = {"error": repr(e)}
     if rank == 0:
         ms = {k: v / max(n_acc, 1) for k, v in stage_acc.items()}  # per step, whole batch of this rank
         value = 2.0 * args.steps * world * B * px_chunk / elapsed / 1e6
@@ -460,6 +551,8 @@ def main(argv=None) -> None:
                 pass
         if verdict is not None:
             result["cpu_baseline"] = verdict
+        if host_api is not None:
+            result["host_api"] = host_api
         _RESULT_OUT.write(json.dumps(result) + "\n")
         _RESULT_OUT.flush()
     if use_dist:

@@ -1,5 +1,5 @@
 """Builds profiles/sq_counters.json from the four SQ counter passes of scripts/collect_sq_counters.sh (gpurun_out/sq/p1..p4:
-one 1920x1080x16 chunk, CDF 9/7 q=80, through scripts/profile_run.py 16).  Counters are sums over the 8 XCDs and are
+one 1920x1080xF chunk, CDF 9/7 q=80, through scripts/profile_run.py F; pass F, default 64).  Counters are sums over the 8 XCDs and are
 averaged over the dispatches of a kernel.
 
 valu_issue_frac: share of the VALU issue capacity the kernel used, with the rates scripts/probes/valu_rate_probe.hip
@@ -17,7 +17,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 px = 1920 * 1080 * frames
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in range(1, 5):

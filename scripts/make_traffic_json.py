@@ -1,5 +1,5 @@
 """Builds profiles/traffic.json from the two PMC passes written by scripts/collect_profiles.sh
-(gpurun_out/final/pmc_fetch, gpurun_out/final/pmc_write): HBM bytes per pixel and per launch of every kernel.
+(gpurun_out/final/pmc_fetch, gpurun_out/final/pmc_write; pass the frame count of the profiled chunk): HBM bytes per pixel and per launch of every kernel.
 
 The unit of the two counters as rocprofv3 reports them is found from a kernel with known traffic (inv_t_kernel reads
 exactly 3 bytes of symbols per pixel): it comes out as 1 KB.  On gfx950 FETCH_SIZE reports exactly half of the bytes read, for 4, 8 and 16 bytes per
@@ -13,7 +13,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 px = 1920 * 1080 * frames
 
 
@@ -40,7 +40,7 @@ for k, v in fetch.items():
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/collect_profiles.sh) on "
                  f"scripts/profile_run.py {frames} (one 1920x1080x{frames} chunk, CDF 9/7 q=80); counter unit calibrated on inv_t_kernel's known reads; "
                  "FETCH_SIZE doubled (gfx950 reports exactly half of known reads: scripts/probes/traffic_calib.hip), WRITE_SIZE as is; "
-                 "per-pixel figures scale to the 64-frame chunk",
+                 "the chunk the bench times when run with 64",
        "per_kernel": {}}
 unit = None
 for k in sorted(set(fetch) | set(write)):
