@@ -215,6 +215,19 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+}  // namespace
+// RansDecoder (src/rans.rs:321-326: state, input, pos).  The input is uploaded once, at the first decode, and stays on the
+// device the object was first used on until the object is destroyed (decode() one symbol at a time must not re-send it).
+struct AliceRansDecoder {
+    std::vector<uint8_t> input;
+    uint32_t state = 0;
+    uint64_t pos = 0;
+    bool started = false;
+    DevBuf d_input;
+    int device = -1;
+};
+namespace {
+
 // Entry points that run on a CALLER's stream name it here for the duration of the call: buffers allocated meanwhile
 // remember it (DevBuf::alloc) and drain it before they go back to the pool.  Cleared on return, so that a later call of
 // the same thread never tags its buffers with a stream the caller may have destroyed since.
@@ -268,7 +281,7 @@ struct FastQuantizer { uint64_t reciprocal; uint32_t shift; int32_t step; int32_
 // segment reads front to back in the order finish() wants; finish() = state bytes, then the segments newest first.
 struct AliceRansEncoder { uint32_t state = alice::kRansL; std::vector<std::vector<uint8_t>> segments; uint64_t bytes = 0; };
 // RansDecoder (src/rans.rs:321-326: state, input, pos)
-struct AliceRansDecoder { std::vector<uint8_t> input; uint32_t state = 0; uint64_t pos = 0; bool started = false; };
+struct AliceRansDecoder;   // (defined below DevBuf: the object keeps its device copy of the input between calls)
 
 namespace {
 
@@ -1415,13 +1428,22 @@ int alice_codec_rans_decoder_decode_n(AliceRansDecoder* d, uint64_t n, const uin
     hipStream_t st;
     TRY(get_stream(&st));
     const uint64_t len = d->input.size();
-    DevBuf din, dc, df, dt, dout, ddesc, dres;
-    TRY(din.alloc(len + 16)); TRY(dc.alloc(512)); TRY(df.alloc(512)); TRY(dt.alloc(sizeof(RansTable)));
+    if (d->d_input.p && d->device != tl_device) d->d_input.reset();   // the calling thread moved to another device
+    if (!d->d_input.p) {
+        hipStream_t keep = tl_scope_stream;
+        tl_scope_stream = nullptr;   // the copy outlives this call
+        const int rc = d->d_input.alloc(len + 16);
+        tl_scope_stream = keep;
+        TRY(rc);
+        d->device = tl_device;
+        if (len) HIP_TRY(hipMemcpyAsync(d->d_input.p, d->input.data(), len, hipMemcpyHostToDevice, st));
+    }
+    DevBuf dc, df, dt, dout, ddesc, dres;
+    TRY(dc.alloc(512)); TRY(df.alloc(512)); TRY(dt.alloc(sizeof(RansTable)));
     TRY(dout.alloc(n)); TRY(ddesc.alloc(sizeof(RansDecodeDesc))); TRY(dres.alloc(sizeof(RansResult)));
-    if (len) HIP_TRY(hipMemcpyAsync(din.p, d->input.data(), len, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
-    RansDecodeDesc desc{din.as<uint8_t>(), len, dout.as<uint8_t>(), n, dt.as<RansTable>(), 1u, d->state, d->pos};
+    RansDecodeDesc desc{d->d_input.as<uint8_t>(), len, dout.as<uint8_t>(), n, dt.as<RansTable>(), 1u, d->state, d->pos};
     HIP_TRY(hipMemcpyAsync(ddesc.p, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
     launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
     launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 1, st);

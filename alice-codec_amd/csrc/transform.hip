@@ -255,16 +255,24 @@ __device__ __forceinline__ void fwd_xy_tile(const FwdXy& a, int bx, int by, int 
 #pragma unroll
             for (int r = 0; r < ER; ++r) v[r] = (int)(short)(L[r * F_LP] >> sh);
             lift_regs<ER, NS, false, false>(v, cf);
-            // band slot: frame plane = rows x pw, low rows of the band first, then its high rows
-            int16_t* out = a.mid + ((size_t)ch * d.pf + t) * ((size_t)a.rows * pw) + (size_t)par * hw + gxp;
+            // band slot: frame plane = rows x pw, low rows of the band first, then its high rows.  Channel and column
+            // parity are the same for all 64 lanes of a wave (128 threads per channel, 64 per parity), so everything but the
+            // lane's own column is WAVE-UNIFORM: the row pointers live in scalar registers and advance by scalar adds, the
+            // lane adds a constant 32-bit offset (global_store saddr form) -- instead of one 64-bit vector add per stored
+            // row (43 v_lshl_add_u64 per thread in the round-2 kernel)
+            const int ch_u = __builtin_amdgcn_readfirstlane(ch), par_u = __builtin_amdgcn_readfirstlane(par);
             const int ly0 = (gy0 - a.y0) >> 1;   // gy0 and y0 are even
+            char* const row0 = (char*)(a.mid + ((size_t)ch_u * d.pf + t) * ((size_t)a.rows * pw) + (size_t)par_u * hw + gx0 / 2 +
+                                       (size_t)ly0 * pw);
+            const uint32_t lane_off = (uint32_t)j * 2u;
+            const size_t pitch = (size_t)pw * 2, half_off = (size_t)hr * pw * 2;
             int acc = 0;
 #pragma unroll
             for (int k = 0; k < F_TH; ++k) {
                 if (!EDGE || gy0 + k < ph) {
-                    const int yy = (k & 1) * hr + ly0 + (k >> 1);
-                    if (PROBE & 2) acc ^= v[H + k] + yy;
-                    else out[(size_t)yy * pw] = (int16_t)v[H + k];
+                    char* const rowp = row0 + (size_t)(k >> 1) * pitch + ((k & 1) ? half_off : 0);   // uniform
+                    if (PROBE & 2) acc ^= v[H + k] + k;
+                    else *(int16_t*)(rowp + lane_off) = (int16_t)v[H + k];
                 }
             }
             if ((PROBE & 2) && acc == 0x5EEDF00D) a.mid[0] = (int16_t)acc;   // (keeps the checksum alive; a valid address whatever the tile)
@@ -690,6 +698,8 @@ struct InvXy {
 // and runs the inverse column lifting in registers.  Rows and columns outside the frame are read through the symmetric
 // extension (reflect_idx), in the interleaved index space, so neither stage needs boundary logic in its arithmetic;
 // rows that only feed never-stored outputs of overhanging tiles are clamped into the slot.
+// (Scalar row pointers plus a 32-bit lane offset here, as the forward tile's stores have them, measured no gain -- 435 vs
+// 431 us -- and giving every channel 128 threads so that the channel is wave-uniform too was 6 % slower: DESIGN.md 4.0.)
 template <int NS, int ER, bool EDGE, bool EXACT, typename MidT, int PROBE = 0>
 __device__ __forceinline__ void inv_load_lift_column(const InvXy& a, int ch, int par, int px, int t, int gy_s, int (&v)[ER]) {
     const ChunkDims& d = a.d;
