@@ -2117,6 +2117,7 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
 // ---- test and measurement hooks (include/alice_codec_test.h) ----
 
 void alice_codec_test_set_tuning(long band_kb) { set_transform_tuning(band_kb); }
+void alice_codec_test_set_value_table_radius(int r) { set_value_table_radius(r); }
 
 int alice_codec_test_chain_occupancy(uint32_t out[6]) {
     clear_error();

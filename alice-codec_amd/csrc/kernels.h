@@ -98,6 +98,8 @@ bool inverse_cuts_chunk(const ChunkDims& d);   // the inverse launches of this s
 void set_transform_probe(int mode);
 // target size of a band slot in KiB (0 = never cut; negative = keep).  Process-wide; meant for tests and probes.
 void set_transform_tuning(long band_kb);
+// radius of the forward temporal kernel's value -> symbol table (clamped to 1 .. 2048, the default).  Process-wide; tests only.
+void set_value_table_radius(int r);
 // Launches of one chunk on `st`, band after band (tile pass then temporal pass; the inverse the other way round).
 // hist: uint32 [3][256], zeroed by the caller.  Returns false (nothing launched) when the shape needs the generic path.
 bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wavelet, int32_t step,

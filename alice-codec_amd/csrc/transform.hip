@@ -295,10 +295,14 @@ __device__ __forceinline__ I4 lift4(const I4& base, const I4& a, const I4& b, in
     return r;
 }
 
-// Histogram bins in LDS: 32 replicas of the 256 bins, word index = symbol * 32 + (lane & 31).  The replica is
-// the bank, so one ds_add is conflict-free up to the two half-waves; the dominant zero symbol (45-90 % of the
-// data) spreads over 32 addresses instead of serialising on one.
-constexpr int kHistReplicas = 32;
+// Histogram bins in LDS: 16 replicas of the 256 bins, word index = symbol * 16 + (lane & 15).  The dominant zero symbol
+// (45-90 % of the data) spreads over 16 addresses instead of serialising on one; 32 replicas (one per bank) make a single
+// ds_add conflict-free but cost 32 KB, and with the 4 KB value table next to them the fifth workgroup per CU: measured
+// 245 us against 241 us for the kernel (profiles/r03_fwd_t_value_table_ab.txt).
+#ifndef ALICE_HIST_REPLICAS
+#define ALICE_HIST_REPLICAS 16
+#endif
+constexpr int kHistReplicas = ALICE_HIST_REPLICAS;
 constexpr int kHistWords = kHistReplicas * 256;
 
 __device__ __forceinline__ uint32_t sat_sub_u32(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
@@ -321,10 +325,28 @@ __device__ __forceinline__ uint32_t quant_sym4(const I4& x, uint32_t hdz, uint32
         // 2q - (v > 0) with floor 0, as 2q + (v < 0) - 1 saturating: v < 0 -> 2q, v > 0 -> 2q - 1, v = 0 -> 0
         const uint32_t t = sat_sub_u32((q << 1) + ((uint32_t)val >> 31), 1u);
         s[i] = t & 0xFFu;                                                          // `as u8`
-        if (HIST) atomicAdd(&lh[(s[i] << 5) + lane_rep], 1u);
+        if (HIST) atomicAdd(&lh[s[i] * kHistReplicas + lane_rep], 1u);
     }
     return s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
 }
+
+// The same map for one value (the table below is filled with it, so table and arithmetic cannot disagree)
+template <bool STEP1>
+__device__ __forceinline__ uint32_t quant_sym1(int val, uint32_t hdz, uint32_t magic) {
+    const uint32_t mag = (uint32_t)max(val, -val);
+    const uint32_t adj = sat_sub_u32(mag, hdz);
+    const uint32_t q = STEP1 ? adj : __umulhi(adj, magic);
+    return sat_sub_u32((q << 1) + ((uint32_t)val >> 31), 1u) & 0xFFu;
+}
+
+// Value -> symbol table in LDS for coefficients in [-r, r), r <= kQLutR: one add and one ds_read_u8 per sample instead of
+// the eight VALU operations above (one of them a quarter-rate multiply).  A wave in which any of a tick's eight values
+// per lane lies outside the table takes the arithmetic path for that tick (wave-uniform branch): same symbols either way.
+// 8-bit RGB cannot leave the table: the largest coefficient the three transforms give it is 2040 (Co of a 0/255
+// checkerboard through CDF 5/3, whose high-pass row has absolute sum 2 per axis; 1.67 for the CDF 9/7 coefficients), so in
+// the product the arithmetic path is a guard, not a path; the suite shrinks r (alice_codec_test_set_value_table_radius)
+// to run it and the boundary between the two.
+constexpr int kQLutR = 2048;
 
 __device__ __forceinline__ I4 unpack4_i16(const uint2 w) {
     I4 r;
@@ -352,6 +374,8 @@ struct FwdT {
     Coeffs cf;
     uint32_t hdz, magic, lane_rep;
     uint32_t* lh;
+    const uint8_t* qlut; // value + qr -> symbol, for values in [-qr, qr)
+    uint32_t qr;
     I4 o1p, e1p, o2pp;
     uint32_t acc;        // PROBE only
 
@@ -366,8 +390,25 @@ struct FwdT {
         o = *(const uint2*)(fe + plane_s * 2 + off16);
     }
     __device__ __forceinline__ void emit(int frame, const I4& lo, const I4& hi) {
-        const uint32_t a = quant_sym4<STEP1, HIST>(lo, hdz, magic, lh, lane_rep);
-        const uint32_t b = quant_sym4<STEP1, HIST>(hi, hdz, magic, lh, lane_rep);
+        uint32_t a, b;
+        uint32_t ix[8], any = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ix[i] = (uint32_t)lo.v[i] + qr; ix[4 + i] = (uint32_t)hi.v[i] + qr; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) any |= ix[i];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any >= 2u * qr) == 0ull, 1)) {
+            uint32_t sy[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sy[i] = qlut[ix[i]];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (HIST) atomicAdd(&lh[sy[i] * kHistReplicas + lane_rep], 1u);
+            a = sy[0] | (sy[1] << 8) | (sy[2] << 16) | (sy[3] << 24);
+            b = sy[4] | (sy[5] << 8) | (sy[6] << 16) | (sy[7] << 24);
+        } else {
+            a = quant_sym4<STEP1, HIST>(lo, hdz, magic, lh, lane_rep);
+            b = quant_sym4<STEP1, HIST>(hi, hdz, magic, lh, lane_rep);
+        }
         if (PROBE & 2) { acc ^= a + (uint32_t)frame; acc ^= b; return; }
         *(uint32_t*)(dst + (size_t)frame * plane_d + off8) = a;
         *(uint32_t*)(dst + (size_t)(half + frame) * plane_d + off8) = b;
@@ -476,14 +517,22 @@ struct FwdTm {
     uint32_t* hist;
     Coeffs cf;
     uint32_t hdz, magic;
+    uint32_t qr;                 // radius of the value -> symbol table (1 .. kQLutR)
     BandT b;
 };
 
 template <int NS, bool STEP1, int PROBE = 0>
 __global__ __launch_bounds__(256) void fwd_t_kernel(FwdTm a) {
     __shared__ uint32_t lh[kHistWords];
+    __shared__ uint8_t qlut[2 * kQLutR];
     const int tid = threadIdx.x;
     for (int i = tid; i < kHistWords; i += 256) lh[i] = 0u;
+    for (int i = tid; i < 2 * kQLutR / 4; i += 256) {
+        uint32_t w = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= quant_sym1<STEP1>(4 * i + j - (int)a.qr, a.hdz, a.magic) << (8 * j);
+        ((uint32_t*)qlut)[i] = w;
+    }
     __syncthreads();
     const int ch = (int)(blockIdx.x / a.b.units_per_ch);
     const uint32_t blk = blockIdx.x % a.b.units_per_ch;
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(256) void fwd_t_kernel(FwdTm a) {
         f.dst = (char*)(a.sym + (size_t)ch * a.b.pf * a.b.plane);
         f.plane_s = a.b.band_px; f.plane_d = a.b.plane;
         f.off16 = idx * 2u; f.off8 = band_plane_index(a.b, idx);
-        f.half = (int)a.b.pf / 2; f.cf = a.cf; f.hdz = a.hdz; f.magic = a.magic; f.lane_rep = (uint32_t)tid & 31u; f.lh = lh;
+        f.half = (int)a.b.pf / 2; f.cf = a.cf; f.hdz = a.hdz; f.magic = a.magic; f.lane_rep = (uint32_t)tid & (kHistReplicas - 1); f.lh = lh; f.qlut = qlut; f.qr = a.qr;
         f.run();
     }
     __syncthreads();
@@ -1151,6 +1200,8 @@ static long& band_target_kb() {
     return kb;
 }
 void set_transform_tuning(long band_kb) { if (band_kb >= 0) band_target_kb() = band_kb; }
+static int g_value_table_radius = kQLutR;
+void set_value_table_radius(int r) { g_value_table_radius = r < 1 ? 1 : (r > kQLutR ? kQLutR : r); }
 // alice_codec_test_transform_ms(probe != 0): the CDF 9/7, step > 1, i16 lane-exchange instances run their probe twins
 static thread_local int tl_valu_probe = 0;
 void set_transform_probe(int mode) { tl_valu_probe = mode; }
@@ -1244,7 +1295,7 @@ bool launch_forward_transform(const uint8_t* d_rgb, const ChunkDims& d, int wave
         xa.bt = BandTiles{(int)nx, by0, nby, 1, (int)ix1, 1, (int)iy1};
         xa.y0 = y0; xa.rows = rows;
         FwdTm ta{};
-        ta.mid = (const int16_t*)d_scratch; ta.sym = d_sym; ta.hist = d_hist; ta.cf = cf; ta.hdz = (uint32_t)step / 2u; ta.magic = magic;
+        ta.mid = (const int16_t*)d_scratch; ta.sym = d_sym; ta.hist = d_hist; ta.cf = cf; ta.hdz = (uint32_t)step / 2u; ta.magic = magic; ta.qr = (uint32_t)g_value_table_radius;
         ta.b = make_band_t(d, (uint32_t)rows * pw, (uint32_t)(rows / 2) * pw, (uint32_t)(y0 / 2) * pw, (hh + (uint32_t)(y0 / 2)) * pw);
         if (probe) {   // loads and stores replaced / loads only / stores only
             if (probe == 1) { fwd_xy_launch<4, 3>(xa, st); fwd_t_launch<4, false, 3>(ta, st); }

@@ -36,6 +36,12 @@ int alice_codec_test_transform_ms(const void *d_rgb, void *d_sym, void *d_rgb_ou
  * many bands; results never depend on it. */
 void alice_codec_test_set_tuning(long band_kb);
 
+/* Radius r of the value -> symbol table of the forward temporal kernel (csrc/transform.hip, kQLutR), process-wide, clamped
+ * to 1 .. 2048 (the default): coefficients in [-r, r) are quantised through the table, a wavefront holding any other value
+ * through the arithmetic.  8-bit RGB never leaves the default table, so the suite shrinks it to run the arithmetic path
+ * and the boundary; results never depend on it. */
+void alice_codec_test_set_value_table_radius(int r);
+
 /* Resident chain kernels: what the runtime reports for the one-chain-per-SIMD instances of the rANS kernels.
  * out[0..2] = encoder: registers per lane (VGPR + AGPR, as allocated), static LDS bytes, workgroups per CU the runtime
  * would co-schedule; out[3..5] = the same for the decoder.  The exclusive instances must report at most 4 workgroups
