@@ -97,7 +97,7 @@ def stream_alc_to_root(get_chunk: Callable[[int], torch.Tensor], sizes: torch.Te
                        sink: Callable[[int, int, torch.Tensor], None], dst: int = 0,
                        group: Optional[dist.ProcessGroup] = None, device=None, depth: int = 2) -> Optional[torch.Tensor]:
     """The gather without a blob on the root: every rank's chunks pass through a small ring of receive slots on rank
-    `dst` and are handed to `sink(rank, chunk_index, bytes)` one at a time (bench.py: a copy on to pinned host memory;
+    `dst` and are handed to `sink(rank, chunk_index, bytes)` one at a time (bench.py: a checksum on the device, optionally a copy on to pinned host memory;
     a real front end: the file or socket the `.alc` stream goes to).  The root's HBM then holds `depth` slots per peer
     (a slot = the largest chunk), not world x chunks x chunk size -- gather_alc_start() with 8 GPUs x 285 chunks x 0.11 GB
     would need 250 GB on rank 0 and used to cap every rank's chunks in flight.
