@@ -61,7 +61,7 @@ for k, c in sorted(acc.items()):
     if cyc > 0:
         d["lds_busy"] = round(d.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * cyc), 3)
         d["lds_bank_conflict_share"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(d.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 3)
-    out["per_kernel"][k] = {n: (round(v, 1) if isinstance(v, float) else v) for n, v in d.items()}
+    out["per_kernel"][k] = {n: (round(v, 3 if abs(v) < 100 else 1) if isinstance(v, float) else v) for n, v in d.items()}
 json.dump(out, open(os.path.join(ROOT, "profiles", "sq_counters.json"), "w"), indent=1)
 for k, d in out["per_kernel"].items():
     if "xy" in k or "_t_" in k:
