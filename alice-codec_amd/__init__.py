@@ -13,6 +13,7 @@ library is missing or no HIP device is usable this module raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import enum
 import os
 
@@ -256,6 +257,18 @@ def _copy_out(ptr, n: int) -> np.ndarray:
     return np.frombuffer((C.c_uint8 * n).from_address(addr), dtype=np.uint8).copy()
 
 
+def _adopt(ptr, n: int, free_fn) -> np.ndarray:
+    """A uint8 array over n bytes the library allocated, without copying them: the array's base owns the C buffer and
+    hands it to free_fn(ptr, n) when the last reference goes (FrameDecoder.decode: 398 MB per 1080p x 64 chunk)."""
+    if n == 0:
+        free_fn(ptr, n)
+        return np.zeros(0, np.uint8)
+    addr = C.cast(ptr, C.c_void_p).value
+    buf = (C.c_uint8 * n).from_address(addr)
+    weakref.finalize(buf, free_fn, addr, n)
+    return np.frombuffer(buf, dtype=np.uint8)
+
+
 def _as_u8(a) -> np.ndarray:
     if isinstance(a, (bytes, bytearray, memoryview)):
         return np.frombuffer(a, dtype=np.uint8)
@@ -431,10 +444,7 @@ class FrameDecoder:
         p = lib.alice_codec_decode64(chunk._h, C.byref(n))
         if not p:
             _raise_last()
-        try:
-            return _copy_out(p, n.value)
-        finally:
-            lib.alice_codec_data_free64(p, n.value)
+        return _adopt(p, n.value, lib.alice_codec_data_free64)
 
 
 def psnr(a, b) -> float:

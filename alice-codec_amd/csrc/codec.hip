@@ -11,14 +11,18 @@
 // device is usable the entry points fail (NULL / error code) -- loudly via
 // alice_codec_last_error().
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -253,6 +257,251 @@ struct DeviceScope {
 };
 
 #define TRY(expr) do { int rc__ = (expr); if (rc__ != kOk) return rc__; } while (0)
+
+// ------------------------------------------------------------------------------------------
+// ChainHub: the chain launches of concurrent host calls, merged
+//
+// A chain kernel runs for seconds and kernels of streams that share a hardware queue run one after the other; the device
+// grants eight queues.  With a stream per calling thread, 64 threads in alice_codec_encode64 therefore had eight chunks'
+// chains running at a time (398 Mpix/s; profiles/r03_host_api_1080p64_8_hw_queues.json) on a GPU that holds 341 chunks'
+// chains.  The whole-chunk host entry points (encode / decode of one chunk, of many chunks) now run like this:
+//   * everything short -- copies, transforms, table builds, stream compaction -- goes to one of kShort streams shared by
+//     all calling threads; nothing on them ever waits for a chain, so they stay short;
+//   * a call hands its chains (descriptors + an event that says their inputs are complete) to the hub and sleeps; one of
+//     the waiting threads, the leader, merges everything that is pending into ONE launch on one of kLanes lane streams and
+//     every member then waits on the host for that launch's event before it queues its own tail on its short stream;
+//   * kShort + kLanes = 7 streams in all, so every one of them owns a hardware queue as long as the host process does not
+//     crowd the eight with streams of its own.
+// Gathering: a call announces itself when it enters (HubTicket) and the leader waits for the announced calls to arrive, but
+// never longer than a tenth of its own chains' run time (a call with a small chunk never waits for a large one's upload);
+// a lone caller launches at once.  When all lanes are busy the pending calls pile up and leave together with the next
+// free lane.  (Round 3 first tried a combiner that kept the callers' own streams: their short work then sat in hardware
+// queues behind other callers' merged chains, and it was slower than no combiner at all:
+// profiles/r03_host_api_1080p64_chain_combiner_rejected.json.)
+// ------------------------------------------------------------------------------------------
+constexpr int kHubShort = 3, kHubLanes = 4, kHubMaxMerged = 1023;   // <= 1023 chains: the one-chain-per-SIMD instances
+
+struct HubLaunch {
+    hipEvent_t done = nullptr;
+    DevBuf descs;
+    std::vector<RansEncodeDesc> enc;      // host copies: alive until the launch is over
+    std::vector<RansDecodeDesc> dec;
+    int rc = kOk;
+    std::string msg;
+    ~HubLaunch() { if (done) (void)hipEventDestroy(done); }
+};
+
+struct HubJob {
+    bool encode = true;
+    std::vector<RansEncodeDesc> enc;
+    std::vector<RansDecodeDesc> dec;
+    hipEvent_t ready = nullptr;           // recorded by the caller on its short stream: the chains' inputs are complete
+    double seconds = 0.0;                 // rough run time of the chains (bounds the gather wait)
+    std::shared_ptr<HubLaunch> launch;    // set by the leader
+    size_t chains() const { return encode ? enc.size() : dec.size(); }
+};
+
+class ChainHub {
+public:
+    static ChainHub* of_device(int device) {
+        static std::mutex mu;
+        static std::map<int, ChainHub*> hubs;   // leaked on purpose: no HIP calls during static destruction
+        std::lock_guard<std::mutex> g(mu);
+        auto it = hubs.find(device);
+        if (it != hubs.end()) return it->second;
+        ChainHub* h = new ChainHub();
+        for (auto& s : h->short_) if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) h->ok_ = false;
+        for (auto& l : h->lanes_) if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) h->ok_ = false;
+        hubs[device] = h;
+        return h;
+    }
+    bool ok() const { return ok_; }
+    hipStream_t short_stream() {
+        static std::atomic<unsigned> next{0};
+        thread_local unsigned mine = next.fetch_add(1u);
+        return short_[mine % kHubShort];
+    }
+    void announce() { std::lock_guard<std::mutex> g(mu_); ++expected_; }
+    void arrived_or_gone() { { std::lock_guard<std::mutex> g(mu_); if (expected_ > 0) --expected_; } cv_.notify_all(); }
+
+    // Hands the job's chains to the next merged launch and returns when they have run.  The caller has recorded job.ready.
+    int run(HubJob& job) {
+        std::unique_lock<std::mutex> lk(mu_);
+        pending_.push_back(&job);
+        cv_.notify_all();
+        while (!job.launch) {
+            if (leader_active_) { cv_.wait(lk); continue; }
+            leader_active_ = true;
+            // gather the announced calls, for at most a tenth of this job's chain time (half a second at most)
+            const auto deadline = std::chrono::steady_clock::now() +
+                                  std::chrono::microseconds((long long)(std::min(0.5, 0.1 * job.seconds) * 1e6));
+            cv_.wait_until(lk, deadline, [&] { return expected_ == 0; });
+            // a free lane (the pending list keeps growing meanwhile)
+            int lane = -1;
+            for (;;) {
+                for (int i = 0; i < kHubLanes && lane < 0; ++i) {
+                    Lane& l = lanes_[(next_lane_ + i) % kHubLanes];
+                    if (!l.last || !l.last->done || l.last->rc != kOk || hipEventQuery(l.last->done) == hipSuccess)
+                        lane = (next_lane_ + i) % kHubLanes;
+                }
+                if (lane >= 0) break;
+                (void)hipGetLastError();   // hipErrorNotReady is not an error
+                cv_.wait_for(lk, std::chrono::milliseconds(1));
+            }
+            next_lane_ = (lane + 1) % kHubLanes;
+            // everything pending of this job's kind, this job first, up to the merged-launch limit
+            std::vector<HubJob*> take{&job};
+            size_t total = job.chains();
+            for (HubJob* j : pending_)
+                if (j != &job && j->encode == job.encode && total + j->chains() <= (size_t)kHubMaxMerged) { take.push_back(j); total += j->chains(); }
+            for (HubJob* j : take) pending_.erase(std::find(pending_.begin(), pending_.end(), j));
+            auto L = std::make_shared<HubLaunch>();
+            lanes_[lane].last = L;
+            lk.unlock();
+            launch(*L, take, lanes_[lane].st, job.encode, total);
+            if (getenv("ALICE_CODEC_DEBUG")) {
+                static const auto t0 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[alice] hub: t=%.3f s, %s launch of %zu calls, %zu chains, lane %d\n",
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), job.encode ? "encode" : "decode",
+                        take.size(), total, lane);
+            }
+            lk.lock();
+            for (HubJob* j : take) j->launch = L;
+            leader_active_ = false;
+            cv_.notify_all();
+        }
+        std::shared_ptr<HubLaunch> L = job.launch;
+        lk.unlock();
+        if (L->rc != kOk) return fail(L->rc, L->msg);
+        HIP_TRY(hipEventSynchronize(L->done));
+        cv_.notify_all();   // a lane has come free
+        return kOk;
+    }
+
+private:
+    struct Lane { hipStream_t st = nullptr; std::shared_ptr<HubLaunch> last; };
+    static void launch(HubLaunch& L, const std::vector<HubJob*>& take, hipStream_t st, bool encode, size_t total) {
+        auto bad = [&](hipError_t e, const char* what) {
+            if (e == hipSuccess || L.rc != kOk) return;
+            L.rc = e == hipErrorOutOfMemory ? (int)kOutOfMemory : (int)kDeviceError;
+            L.msg = std::string(what) + ": " + hipGetErrorString(e);
+        };
+        bad(hipEventCreateWithFlags(&L.done, hipEventDisableTiming), "hipEventCreate");
+        size_t bytes = 0;
+        const void* host = nullptr;
+        if (encode) {
+            L.enc.reserve(total);
+            for (HubJob* j : take) L.enc.insert(L.enc.end(), j->enc.begin(), j->enc.end());
+            bytes = L.enc.size() * sizeof(RansEncodeDesc); host = L.enc.data();
+        } else {
+            L.dec.reserve(total);
+            for (HubJob* j : take) L.dec.insert(L.dec.end(), j->dec.begin(), j->dec.end());
+            bytes = L.dec.size() * sizeof(RansDecodeDesc); host = L.dec.data();
+        }
+        if (L.rc == kOk && L.descs.alloc(bytes) != kOk) { L.rc = kOutOfMemory; L.msg = "descriptor buffer of a merged chain launch"; }
+        L.descs.st = nullptr;   // every member waits for `done` before the launch object dies: nothing to drain then
+        if (L.rc != kOk) return;
+        for (HubJob* j : take) bad(hipStreamWaitEvent(st, j->ready, 0), "hipStreamWaitEvent");
+        bad(hipMemcpyAsync(L.descs.p, host, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync(descriptors)");
+        if (L.rc != kOk) return;
+        if (encode) launch_rans_encode_descs(L.descs.as<RansEncodeDesc>(), (int)total, st);
+        else launch_rans_decode(L.descs.as<RansDecodeDesc>(), nullptr, (int)total, st);
+        bad(hipGetLastError(), "chain launch");
+        bad(hipEventRecord(L.done, st), "hipEventRecord");
+    }
+
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<HubJob*> pending_;
+    int expected_ = 0;
+    bool leader_active_ = false;
+    bool ok_ = true;
+    int next_lane_ = 0;
+    hipStream_t short_[kHubShort] = {nullptr};
+    Lane lanes_[kHubLanes];
+};
+
+// A whole-chunk host call between its entry and the moment its chains are handed over: the hub's leader waits for it.
+struct HubTicket {
+    ChainHub* hub = nullptr;
+    bool counted = false;
+    hipStream_t st = nullptr;
+    int open() {
+        TRY(ensure_device());
+        hub = ChainHub::of_device(tl_device);
+        if (!hub->ok()) return fail(kDeviceError, "the streams of the chain hub could not be created");
+        hub->announce();
+        counted = true;
+        st = hub->short_stream();
+        tl_scope_stream = st;
+        return kOk;
+    }
+    void arrived() { if (counted) { counted = false; hub->arrived_or_gone(); } }
+    ~HubTicket() { arrived(); tl_scope_stream = nullptr; }
+};
+
+// Large device-to-host copies into the caller's pageable memory.  hipMemcpyAsync to pageable memory goes through the
+// runtime's own staging at about 3 GB/s and keeps the stream busy meanwhile (110 MB of .alc: 37 ms; 64 threads' decoded
+// chunks, 25 GB, over three shared streams: most of the call).  Here the copy lands in two pinned pieces of this thread,
+// alternately, at the rate of the link, and the calling thread moves each piece on while the next one is in flight -- so
+// the threads' CPU copies run side by side and the stream carries only the DMA.  Synchronous: returns when dst is filled.
+constexpr size_t kStagePiece = size_t(32) << 20;
+struct HostStage {
+    void* piece[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int device = -1;
+    bool ready() {
+        if (piece[0] && device == tl_device) return true;
+        release();
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&piece[i], kStagePiece, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
+        device = tl_device;
+        return true;
+    }
+    void release() {
+        for (int i = 0; i < 2; ++i) {
+            if (piece[i]) (void)hipHostFree(piece[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            piece[i] = nullptr; ev[i] = nullptr;
+        }
+    }
+    ~HostStage() { release(); }
+};
+thread_local HostStage tl_stage;
+
+int copy_to_host(void* dst, const void* d_src, size_t bytes, hipStream_t st) {
+    if (bytes < (size_t(4) << 20) || !tl_stage.ready()) {
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return kOk;
+    }
+    const size_t n = (bytes + kStagePiece - 1) / kStagePiece;
+    auto len = [&](size_t k) { return std::min(kStagePiece, bytes - k * kStagePiece); };
+    for (size_t k = 0; k <= n; ++k) {
+        if (k < n) {
+            HIP_TRY(hipMemcpyAsync(tl_stage.piece[k & 1], (const uint8_t*)d_src + k * kStagePiece, len(k), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(tl_stage.ev[k & 1], st));
+        }
+        if (k >= 1) {
+            HIP_TRY(hipEventSynchronize(tl_stage.ev[(k - 1) & 1]));
+            memcpy((uint8_t*)dst + (k - 1) * kStagePiece, tl_stage.piece[(k - 1) & 1], len(k - 1));
+        }
+    }
+    return kOk;
+}
+
+// records `ready` on st, runs the job through the hub, destroys the event
+int hub_run(HubTicket& t, HubJob& job, hipStream_t st) {
+    HIP_TRY(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
+    int rc = kOk;
+    if (hipEventRecord(job.ready, st) != hipSuccess) rc = fail(kDeviceError, "hipEventRecord failed");
+    t.arrived();
+    if (rc == kOk) rc = t.hub->run(job);
+    (void)hipEventDestroy(job.ready);
+    job.ready = nullptr;
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------
 // chunk object and .alc (de)serialisation
@@ -504,7 +753,7 @@ struct StageEvents {
 //   kCapWorst    2 bytes per symbol, the bound of the format (the last resort: 3 x 2 x padded bytes per chunk).
 enum CapMode { kCapReuse = 0, kCapEstimate = 1, kCapWorst = 2 };
 int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wavelet, hipStream_t st,
-                  StageEvents* evs, CapMode mode = kCapReuse) {
+                  StageEvents* evs, CapMode mode = kCapReuse, HubTicket* hub = nullptr) {
     const ChunkDims& d = w.d;
     const int32_t step = quality_to_step(quality);
     const int B = w.n_chunks;
@@ -538,8 +787,28 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
     TRY(encode_work_set_cap(w, cap));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
     if (evs) HIP_TRY(hipEventRecord(evs->ev[2], st));
-    launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.alc.as<uint8_t>(),
-                       w.cap[0], w.results.as<RansResult>(), 3 * B, st, w.alc_stride, kStreamHead, 0xFFFFFFFFu, w.cap[1], w.cap[2]);
+    if (hub) {
+        // host call: the chains leave with the hub's next merged launch (same regions as the grouped layout below); this
+        // thread sleeps until they have run and then queues the tail on its short stream
+        HubJob job;
+        job.encode = true;
+        job.enc.resize((size_t)3 * B);
+        for (int c = 0; c < 3 * B; ++c) {
+            RansEncodeDesc& e = job.enc[(size_t)c];
+            const int g = c % 3;
+            e.sym = w.sym.as<uint8_t>() + (size_t)c * d.padded;
+            e.n = d.padded;
+            e.table = w.tables.as<RansTable>() + c;
+            e.region = w.alc.as<uint8_t>() + (size_t)(c / 3) * w.alc_stride + kStreamHead + (g == 0 ? 0ull : (g == 1 ? w.cap[0] : w.cap[0] + w.cap[1]));
+            e.cap = w.cap[g];
+            e.result = w.results.as<RansResult>() + c;
+        }
+        job.seconds = (double)d.padded * 21e-9;
+        TRY(hub_run(*hub, job, st));
+    } else {
+        launch_rans_encode(w.sym.as<uint8_t>(), d.padded, d.padded, w.tables.as<RansTable>(), w.alc.as<uint8_t>(),
+                           w.cap[0], w.results.as<RansResult>(), 3 * B, st, w.alc_stride, kStreamHead, 0xFFFFFFFFu, w.cap[1], w.cap[2]);
+    }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[3], st));
     launch_write_headers(w.alc.as<uint8_t>(), w.alc_stride, d, wavelet, step, w.hist.as<uint32_t>(),
                          w.results.as<RansResult>(), w.sizes.as<unsigned long long>(), B, st);
@@ -616,7 +885,7 @@ int inverse_generic(const uint8_t* d_sym, const ChunkDims& d, int wavelet, const
 // headers[b]: parsed chunk headers (validated); d_payload[b]: device pointer to chunk b's payload;
 // d_rgb[b]: where chunk b's pixels go
 int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<const uint8_t*>& d_payload,
-                  DecodeWork& w, const std::vector<uint8_t*>& d_rgb, hipStream_t st, StageEvents* evs) {
+                  DecodeWork& w, const std::vector<uint8_t*>& d_rgb, hipStream_t st, StageEvents* evs, HubTicket* hub = nullptr) {
     const ChunkDims& d = w.d;
     const int B = w.n_chunks;
     if (transform_tiles_eligible(d)) {
@@ -651,11 +920,20 @@ int decode_launch(const std::vector<EncodedChunk>& headers, const std::vector<co
         }
     }
     HIP_TRY(hipMemcpyAsync(w.hist.p, hist.data(), hist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w.descs.p, descs.data(), descs.size() * sizeof(RansDecodeDesc), hipMemcpyHostToDevice, st));
+    if (!hub) HIP_TRY(hipMemcpyAsync(w.descs.p, descs.data(), descs.size() * sizeof(RansDecodeDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // host vectors go out of scope
     if (evs) HIP_TRY(hipEventRecord(evs->ev[5], st));
     launch_rans_table(w.hist.as<uint32_t>(), w.tables.as<RansTable>(), 3 * B, st);
-    launch_rans_decode(w.descs.as<RansDecodeDesc>(), w.results.as<RansResult>(), 3 * B, st);
+    if (hub) {   // host call: see encode_launch
+        HubJob job;
+        job.encode = false;
+        job.dec = std::move(descs);
+        for (size_t c = 0; c < job.dec.size(); ++c) job.dec[c].result = w.results.as<RansResult>() + c;
+        job.seconds = (double)d.padded * 39e-9;
+        TRY(hub_run(*hub, job, st));
+    } else {
+        launch_rans_decode(w.descs.as<RansDecodeDesc>(), w.results.as<RansResult>(), 3 * B, st);
+    }
     if (evs) HIP_TRY(hipEventRecord(evs->ev[6], st));
     {
         const bool tiles = transform_tiles_eligible(d) && w.scratch->p;
@@ -723,8 +1001,9 @@ int encode_host(const FrameEncoder& enc, const uint8_t* rgb, uint64_t rgb_len, u
     const ChunkDims d = make_dims(width, height, frames);
     if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count does not fit the header's u32 num_symbols");
 
-    hipStream_t st;
-    TRY(get_stream(&st));
+    HubTicket ticket;
+    TRY(ticket.open());
+    const hipStream_t st = ticket.st;
     DevBuf d_rgb;
     TRY(d_rgb.alloc(rgb_len));
     HIP_TRY(hipMemcpyAsync(d_rgb.p, rgb, rgb_len, hipMemcpyHostToDevice, st));
@@ -732,30 +1011,46 @@ int encode_host(const FrameEncoder& enc, const uint8_t* rgb, uint64_t rgb_len, u
     std::vector<RansResult> res;
     TRY(encode_work_alloc(w, d, 1));
     for (int attempt = 0;; ++attempt) {
-        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt));
+        TRY(encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt, &ticket));
         int rc = encode_collect(w, st, res);
         if (rc == kOk) break;
         if (rc != -1 || attempt >= 2) return rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc;
     }
     uint64_t payload = res[0].len + res[1].len + res[2].len;
-    std::vector<uint8_t> alc((size_t)kAlcHeaderBytes + payload);
-    HIP_TRY(hipMemcpyAsync(alc.data(), w.alc.p, alc.size(), hipMemcpyDeviceToHost, st));
+    // the header into a small buffer, the payload straight into the chunk object (one allocation, one pass over it)
+    std::vector<uint8_t> hdr((size_t)kAlcHeaderBytes);
+    HIP_TRY(hipMemcpyAsync(hdr.data(), w.alc.p, hdr.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t tot = 0;
-    TRY(parse_alc_header(alc.data(), alc.size(), out, &tot));
+    TRY(parse_alc_header(hdr.data(), hdr.size() + payload, out, &tot));
     if (tot != payload) return fail(kInternal, "device header/payload length mismatch");
-    out.data.assign(alc.begin() + kAlcHeaderBytes, alc.end());
+    out.data.resize((size_t)payload);
+    TRY(copy_to_host(out.data.data(), w.alc.as<uint8_t>() + kAlcHeaderBytes, (size_t)payload, st));
     return kOk;
 }
 
 // FrameDecoder::decode on a host chunk (src/pipeline.rs:537-624)
-int decode_host(const EncodedChunk& c, std::vector<uint8_t>& rgb) {
+// A buffer the C ABI hands to the caller (released with free(): alice_codec_data_free64).  Large ones are 2 MiB aligned and
+// marked for huge pages: 64 threads that each fault a fresh 398 MB result in 4 KiB pages spend more time in the kernel's
+// page-fault path than the GPU spends on their chains.
+uint8_t* host_result_alloc(uint64_t bytes) {
+    constexpr size_t kHuge = size_t(2) << 20;
+    if (bytes < 2 * kHuge) return (uint8_t*)malloc(bytes ? (size_t)bytes : 1);
+    const size_t len = round_up(bytes, kHuge);
+    void* p = aligned_alloc(kHuge, len);
+    if (p) (void)madvise(p, len, MADV_HUGEPAGE);
+    return (uint8_t*)p;
+}
+
+// *out: malloc'ed pixels (nullptr for an empty chunk), *out_len their count
+int decode_host(const EncodedChunk& c, uint8_t** out, uint64_t* out_len) {
     ChunkDims d;
     TRY(validate_for_decode(c, &d, c.data.size()));
-    rgb.clear();
-    if (d.n_pixels == 0) return kOk;
-    hipStream_t st;
-    TRY(get_stream(&st));
+    *out = nullptr; *out_len = 0;
+    if (d.n_pixels == 0) { *out = host_result_alloc(0); return *out ? kOk : fail(kOutOfMemory, "out of host memory"); }
+    HubTicket ticket;
+    TRY(ticket.open());
+    const hipStream_t st = ticket.st;
     DevBuf d_payload, d_rgb;
     TRY(d_payload.alloc(c.data.size() + 16));
     TRY(d_rgb.alloc(d.n_pixels * 3));
@@ -767,11 +1062,13 @@ int decode_host(const EncodedChunk& c, std::vector<uint8_t>& rgb) {
     hdrs[0].width = c.width; hdrs[0].height = c.height; hdrs[0].frames = c.frames; hdrs[0].wavelet = c.wavelet;
     for (int k = 0; k < 3; ++k) hdrs[0].ch[k] = c.ch[k];
     std::vector<const uint8_t*> pay(1, d_payload.as<uint8_t>());
-    TRY(decode_launch(hdrs, pay, w, std::vector<uint8_t*>(1, d_rgb.as<uint8_t>()), st, nullptr));
+    TRY(decode_launch(hdrs, pay, w, std::vector<uint8_t*>(1, d_rgb.as<uint8_t>()), st, nullptr, &ticket));
     TRY(decode_collect(w, st));
-    rgb.resize(d.n_pixels * 3);
-    HIP_TRY(hipMemcpyAsync(rgb.data(), d_rgb.p, rgb.size(), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    uint8_t* rgb = host_result_alloc(d.n_pixels * 3);
+    if (!rgb) return fail(kOutOfMemory, "out of host memory");
+    const int rc = copy_to_host(rgb, d_rgb.p, d.n_pixels * 3, st);
+    if (rc != kOk) { free(rgb); return rc; }
+    *out = rgb; *out_len = d.n_pixels * 3;
     return kOk;
 }
 
@@ -900,11 +1197,8 @@ EncodedChunk* alice_codec_encode(const FrameEncoder* encoder, const uint8_t* rgb
 uint8_t* alice_codec_decode64(const EncodedChunk* chunk, uint64_t* out_len) {
     clear_error();
     if (!chunk || !out_len) { fail(kNullArgument, "null argument"); return nullptr; }
-    std::vector<uint8_t> rgb;
-    if (decode_host(*chunk, rgb) != kOk) return nullptr;
-    uint8_t* p = to_c_buffer(rgb);
-    if (!p) { fail(kOutOfMemory, "out of host memory"); return nullptr; }
-    *out_len = rgb.size();
+    uint8_t* p = nullptr;
+    if (decode_host(*chunk, &p, out_len) != kOk) return nullptr;
     return p;
 }
 uint8_t* alice_codec_decode(const EncodedChunk* chunk, uint32_t* out_len) {
@@ -1749,8 +2043,9 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
     const uint32_t n = (uint32_t)rgb.size();
     for (uint32_t i = 0; i < n; ++i) *out[i] = nullptr;
     if (!n) return kOk;
-    hipStream_t st;
-    TRY(get_stream(&st));
+    HubTicket ticket;
+    TRY(ticket.open());
+    const hipStream_t st = ticket.st;
     auto undo = [&](int rc) { for (uint32_t k = 0; k < n; ++k) { delete *out[k]; *out[k] = nullptr; } return rc; };
     const uint64_t chunk_bytes = d.n_pixels * 3;
     const uint32_t per_pass = chunks_that_fit(d, n);
@@ -1766,27 +2061,27 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
             if (hipMemcpyAsync(d_rgb.as<uint8_t>() + (size_t)i * chunk_bytes, rgb[first + i], chunk_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
                 return undo(fail(kDeviceError, "host to device copy failed"));
         for (int attempt = 0;; ++attempt) {
-            rc = encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt);
+            rc = encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt, &ticket);
             if (rc != kOk) return undo(rc);
             rc = encode_collect(w, st, res);
             if (rc == kOk) break;
             if (rc != -1 || attempt >= 2) return undo(rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc);
         }
-        std::vector<uint8_t> alc;
+        std::vector<uint8_t> hdr((size_t)kAlcHeaderBytes);
         for (uint32_t i = 0; i < B; ++i) {
             const uint64_t payload = res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
-            alc.resize((size_t)kAlcHeaderBytes + payload);
-            if (hipMemcpyAsync(alc.data(), w.alc.as<uint8_t>() + (size_t)i * w.alc_stride, alc.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess)
+            const uint8_t* d_alc = w.alc.as<uint8_t>() + (size_t)i * w.alc_stride;
+            if (hipMemcpyAsync(hdr.data(), d_alc, hdr.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
                 return undo(fail(kDeviceError, "device to host copy failed"));
             EncodedChunk* c = new (std::nothrow) EncodedChunk();
             uint64_t tot = 0;
-            if (!c || parse_alc_header(alc.data(), alc.size(), *c, &tot) != kOk || tot != payload) {
+            if (!c || parse_alc_header(hdr.data(), hdr.size() + payload, *c, &tot) != kOk || tot != payload) {
                 delete c;
                 return undo(fail(kInternal, "device header/payload length mismatch"));
             }
-            c->data.assign(alc.begin() + kAlcHeaderBytes, alc.end());
-            *out[first + i] = c;
+            *out[first + i] = c;   // (undo() deletes it from here on)
+            c->data.resize((size_t)payload);
+            if (copy_to_host(c->data.data(), d_alc + kAlcHeaderBytes, (size_t)payload, st) != kOk) return undo(tl_err);
         }
     }
     return kOk;
@@ -1796,8 +2091,9 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
 static int decode_chunks_on_device(const std::vector<const EncodedChunk*>& chunks, const ChunkDims& d, const std::vector<uint8_t*>& rgb_out) {
     const uint32_t n = (uint32_t)chunks.size();
     if (!n || d.n_pixels == 0) return kOk;
-    hipStream_t st;
-    TRY(get_stream(&st));
+    HubTicket ticket;
+    TRY(ticket.open());
+    const hipStream_t st = ticket.st;
     const uint64_t chunk_bytes = d.n_pixels * 3;
     const uint32_t per_pass = chunks_that_fit(d, n);
     for (uint32_t first = 0; first < n; first += per_pass) {
@@ -1826,11 +2122,9 @@ static int decode_chunks_on_device(const std::vector<const EncodedChunk*>& chunk
         }
         DecodeWork w;
         TRY(decode_work_alloc(w, d, (int)B));
-        TRY(decode_launch(hdrs, pay, w, dst, st, nullptr));
+        TRY(decode_launch(hdrs, pay, w, dst, st, nullptr, &ticket));
         TRY(decode_collect(w, st));
-        for (uint32_t i = 0; i < B; ++i)
-            HIP_TRY(hipMemcpyAsync(rgb_out[first + i], dst[i], chunk_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < B; ++i) TRY(copy_to_host(rgb_out[first + i], dst[i], chunk_bytes, st));
     }
     return kOk;
 }

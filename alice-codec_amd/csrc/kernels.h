@@ -44,6 +44,20 @@ struct RansDecodeDesc {
     // position of the next stream byte instead of the four head bytes
     uint32_t resume, x0;
     unsigned long long pos0;
+    // where the chain's result goes; null: results[chain] of the launch.  (Chains of several callers merged into one
+    // launch -- codec.hip, ChainHub -- report into their callers' own buffers.)
+    RansResult* result;
+};
+
+// One encode chain of a merged launch (launch_rans_encode_descs): what launch_rans_encode derives from a base, strides and
+// the chain number, spelled out per chain.
+struct RansEncodeDesc {
+    const uint8_t* sym;       // n symbols
+    unsigned long long n;
+    const RansTable* table;
+    uint8_t* region;          // the stream is written back to front into [region, region + cap)
+    unsigned long long cap;
+    RansResult* result;
 };
 
 // ---- rans.hip ----
@@ -72,6 +86,8 @@ void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t str
 void launch_merge4(const uint8_t* d_in, uint64_t stride, const uint64_t have[4], const uint64_t count[4], uint8_t* d_out,
                    uint64_t n_out, hipStream_t st);
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
+// chains described one by one (fresh encoders: state 2^23, finish() bytes written); every desc names its result
+void launch_rans_encode_descs(const RansEncodeDesc* d_descs, int n_chains, hipStream_t st);
 // what the runtime reports for the one-chain-per-SIMD instances: out[0..2] = encoder registers per lane (VGPR + AGPR),
 // static LDS bytes, workgroups per CU it would co-schedule; out[3..5] = decoder.  False when a query failed.
 bool chain_kernel_occupancy(uint32_t out[6]);

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
                                                          unsigned n_split,
                                                          RansResult* __restrict__ results,
                                                          unsigned long long cap1, unsigned long long cap2,
-                                                         uint32_t x_init, uint32_t keep_open, uint32_t take_turns) {
+                                                         uint32_t x_init, uint32_t keep_open, uint32_t take_turns,
+                                                         const RansEncodeDesc* __restrict__ descs) {
     __shared__ uint4 tab_a[256];  // xmax, xmax8, rcp, rsh
     __shared__ uint4 tab_b[256];  // g, cbias, freq, cum
     __shared__ __attribute__((aligned(16))) uint8_t tile[kEncTile];
@@ -311,16 +312,21 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     const int chain = blockIdx.x;
     const int lane = threadIdx.x;
     // chains from n_split on carry one symbol less (the sub-sequences of an interleaved stream)
-    const unsigned long long n = n_first - (((unsigned)chain >= n_split && n_first > 0ull) ? 1ull : 0ull);
+    unsigned long long n = n_first - (((unsigned)chain >= n_split && n_first > 0ull) ? 1ull : 0ull);
     const uint8_t* __restrict__ sym = sym_base + (size_t)chain * sym_stride;
     const RansTable* __restrict__ tbl = tables + chain;
     // group_stride == 0: regions back to back.  Otherwise the three chains of chunk g write into the chunk's own
     // .alc buffer, behind `group_head` bytes kept free for the header (the streams are compacted in place later).
     const int gch = chain % 3;
-    const unsigned long long cap = group_stride == 0ull ? cap0 : (gch == 0 ? cap0 : (gch == 1 ? cap1 : cap2));
-    uint8_t* const region = group_stride == 0ull ? out_base + (size_t)chain * cap0
-                                                 : out_base + (size_t)(chain / 3) * group_stride + group_head +
-                                                       (gch == 0 ? 0ull : (gch == 1 ? cap0 : cap0 + cap1));
+    unsigned long long cap = group_stride == 0ull ? cap0 : (gch == 0 ? cap0 : (gch == 1 ? cap1 : cap2));
+    uint8_t* region = group_stride == 0ull ? out_base + (size_t)chain * cap0
+                                           : out_base + (size_t)(chain / 3) * group_stride + group_head +
+                                                 (gch == 0 ? 0ull : (gch == 1 ? cap0 : cap0 + cap1));
+    RansResult* res = results + chain;
+    if (descs) {   // a merged launch (launch_rans_encode_descs): every chain spelled out
+        const RansEncodeDesc ds = descs[chain];
+        sym = ds.sym; n = ds.n; tbl = ds.table; region = ds.region; cap = ds.cap; res = ds.result;
+    }
     uint8_t* const out_end = region + cap;
     // lanes that have nothing to emit store to a private byte at the unused front of the region instead
     // of branching around the store; the capacity test keeps real bytes 64 bytes away from it
@@ -499,15 +505,15 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
         written += 4ull;
     }
     if (lane == 0) {
-        results[chain].len = written;
-        results[chain].flags = flags;
-        results[chain].final_state = x;
-        results[chain].fast_tiles = 0u;
-        results[chain].slow_tiles = 0u;
-        results[chain].cycles_k = (uint32_t)((clock64() - clk0) >> 10);
-        results[chain].ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
-        results[chain].hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        results[chain].xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        res->len = written;
+        res->flags = flags;
+        res->final_state = x;
+        res->fast_tiles = 0u;
+        res->slow_tiles = 0u;
+        res->cycles_k = (uint32_t)((clock64() - clk0) >> 10);
+        res->ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
+        res->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        res->xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 }
 
@@ -770,16 +776,17 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansDecodeDesc* _
         while (x < kRansL && pos < len) { x = (x << 8) | (uint32_t)d.in[pos]; pos += 1ull; }
     }
     if (lane == 0) {
-        results[blockIdx.x].len = pos;
-        results[blockIdx.x].flags = flags;
-        results[blockIdx.x].final_state = x;
-        results[blockIdx.x].fast_tiles = n_fast;
-        results[blockIdx.x].slow_tiles = n_slow;
-        results[blockIdx.x].paths = paths;
-        results[blockIdx.x].cycles_k = (uint32_t)((clock64() - clk0) >> 10);
-        results[blockIdx.x].ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
-        results[blockIdx.x].hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        results[blockIdx.x].xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        RansResult* const res = d.result ? d.result : results + blockIdx.x;
+        res->len = pos;
+        res->flags = flags;
+        res->final_state = x;
+        res->fast_tiles = n_fast;
+        res->slow_tiles = n_slow;
+        res->paths = paths;
+        res->cycles_k = (uint32_t)((clock64() - clk0) >> 10);
+        res->ticks_k = (uint32_t)((wall_clock64() - rt0) >> 10);
+        res->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        res->xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 }
 
@@ -860,7 +867,16 @@ void launch_rans_encode(const uint8_t* d_sym, uint64_t sym_stride, uint64_t n, c
                        (unsigned long long)sym_stride, (unsigned long long)n, d_tables, d_out,
                        (unsigned long long)cap, (unsigned long long)group_stride, (unsigned long long)group_head, n_split,
                        d_results, (unsigned long long)(cap_co ? cap_co : cap), (unsigned long long)(cap_cg ? cap_cg : cap),
-                       x_init, keep_open ? 1u : 0u, chain_turns_enabled());
+                       x_init, keep_open ? 1u : 0u, chain_turns_enabled(), (const RansEncodeDesc*)nullptr);
+}
+
+void launch_rans_encode_descs(const RansEncodeDesc* d_descs, int n_chains, hipStream_t st) {
+    if (n_chains <= 0) return;
+    auto kern = n_chains <= 1024 ? rans_encode_kernel<true> : rans_encode_kernel<false>;
+    const ChainKernelFacts& facts = chain_kernel_facts();
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(64), chain_lds_pad(n_chains, facts.ok ? facts.enc_lds_plain : 9216u), st,
+                       (const uint8_t*)nullptr, 0ull, 0ull, (const RansTable*)nullptr, (uint8_t*)nullptr, 0ull, 0ull, 0ull, 0xFFFFFFFFu,
+                       (RansResult*)nullptr, 0ull, 0ull, kRansL, 0u, chain_turns_enabled(), d_descs);
 }
 
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st) {
