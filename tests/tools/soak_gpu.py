@@ -153,10 +153,20 @@ def batch_case(rng, seed):
     bt = a.Batch(w, h, f, B, q, a.WaveletType(k))
     st = torch.cuda.current_stream().cuda_stream
     ok = True
+    try:
+        refs = [o.encode(c, w, h, f, q, k) for c in chunks]
+    except o.OracleError:      # a chunk the reference does not terminate on: the batch must refuse it too
+        try:
+            bt.encode(rgb.data_ptr(), st); bt.encode_finish()
+            refused = False
+        except a.CodecError:
+            refused = True
+        note("batch-diverges", refused, ("batch-diverges", seed, w, h, f, B, k, q))
+        del bt
+        return
     for rep in range(2):
         bt.encode(rgb.data_ptr(), st)
         sizes = bt.encode_finish()
-        refs = [o.encode(c, w, h, f, q, k) for c in chunks]
         for i in range(B):
             t = torch.empty(int(sizes[i]), dtype=torch.uint8, device="cuda")
             hip.hipMemcpy(t.data_ptr(), bt.alc_ptr(i), int(sizes[i]), 3)
