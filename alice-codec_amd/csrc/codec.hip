@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -358,7 +359,11 @@ public:
             auto L = std::make_shared<HubLaunch>();
             lanes_[lane].last = L;
             lk.unlock();
-            launch(*L, take, lanes_[lane].st, job.encode, total);
+            try {
+                launch(*L, take, lanes_[lane].st, job.encode, total);
+            } catch (const std::exception& e) {   // host allocation failure while merging the descriptors
+                L->rc = kOutOfMemory; L->msg = std::string("merged chain launch: ") + e.what();
+            }
             if (getenv("ALICE_CODEC_DEBUG")) {
                 static const auto t0 = std::chrono::steady_clock::now();
                 fprintf(stderr, "[alice] hub: t=%.3f s, %s launch of %zu calls, %zu chains, lane %d\n",

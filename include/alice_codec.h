@@ -16,7 +16,10 @@
  * to_symbols/from_symbols/build_histogram, FrequencyTable, RansEncoder/RansDecoder, colour).
  *
  * Handles are opaque and immutable after creation; encode/decode may be called from many
- * threads on the same handle (reference: Send + Sync, src/pipeline.rs:635-644).
+ * threads on the same handle (reference: Send + Sync, src/pipeline.rs:635-644).  Concurrent
+ * encode / decode calls scale: the serial entropy chains of all calls in flight leave in merged
+ * kernel launches (chain hub), so a thread pool over chunks keeps as many
+ * chunks' chains running as the device holds, not one per hardware queue.
  */
 #ifndef ALICE_CODEC_H
 #define ALICE_CODEC_H
@@ -116,7 +119,7 @@ int alice_codec_decode_many(const EncodedChunk *const *chunks, uint32_t n_chunks
  *
  * The same over several GPUs of the node, for hosts that are not Python (the chunk driver of src/pipeline.rs:461-497:
  * 64-frame chunks are independent bitstreams).  Chunk k runs on devices[k mod n_devices]; the library starts one host
- * thread with one HIP stream per entry of the list, every device copies its own chunks in and its own results out (its
+ * thread per entry of the list, every device copies its own chunks in and its own results out (its
  * own PCIe link; nothing is staged on another GPU), and results arrive in chunk order.  A device may be listed more than
  * once (two host threads sharing it).  Byte-identical to alice_codec_encode_many / decode_many for every device list.
  * alice_codec_many_devices_plan fills device_of_chunk[n_chunks] with that assignment (no device is touched). */
