@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of transform builds under rocprofv3 (ab_libs/*.so named on the command line) + parity of the in-tree build
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r3l; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/ab; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bands.py -x -q -m gpu > $OUT/tests.log 2>&1; rc=$?; echo "tests rc=$rc"
 tail -5 $OUT/tests.log
 if [ $rc -ne 0 ]; then exit 1; fi
@@ -11,7 +11,7 @@ for L in "$@"; do
 done
 python - <<'PY'
 import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/r3l/*/*/*_kernel_trace.csv')):
+for f in sorted(glob.glob('gpurun_out/ab/*/*/*_kernel_trace.csv')):
     print(f.split('/')[2])
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Full GPU suite + one-rank rehearsal of the bench's distributed path (both gather sinks) + the loud failure of --gpus 2 on a 1-GPU box
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r3o; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/rehearsal; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 800 python -m pytest tests -x -q -m gpu > $OUT/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -4 $OUT/tests.log
 if [ $rc -ne 0 ]; then exit 1; fi
 for sink in device host; do

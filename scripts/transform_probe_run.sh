@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r3m; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/probe_twins; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 700 python -m pytest tests/test_gpu_value_table.py tests/test_gpu_parity.py tests/test_gpu_bands.py -x -q -m gpu > $OUT/tests.log 2>&1; rc=$?; echo "tests rc=$rc"
 tail -5 $OUT/tests.log
 if [ $rc -ne 0 ]; then exit 1; fi
@@ -8,7 +8,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/sweep -- 
 grep band_kb $OUT/sweep.log
 python - <<'PY'
 import csv, glob, collections
-for f in glob.glob('gpurun_out/r3m/sweep/*/*_kernel_trace.csv'):
+for f in glob.glob('gpurun_out/probe_twins/sweep/*/*_kernel_trace.csv'):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
