@@ -21,6 +21,22 @@ import alice_codec_amd as a  # noqa: E402
 a.set_device(0)
 res = bench.host_api_measure(threads)
 W, H, F = bench.W, bench.H, bench.F
+if os.environ.get("ALICE_PROBE_MANY"):
+    # the many-chunk entry points from ONE thread: n chunks in host memory, one call each way
+    import numpy as np
+    n = int(os.environ["ALICE_PROBE_MANY"])
+    dev = torch.device("cuda:0")
+    rgb = np.stack([bench.synth_chunk(dev, 5000 + i).reshape(-1).cpu().numpy() for i in range(n)])
+    torch.cuda.empty_cache()
+    enc = a.FrameEncoder.with_wavelet(bench.QUALITY, bench.WAVELET)
+    t0 = time.perf_counter(); chunks = a.encode_many(enc, rgb, W, H, F); t1 = time.perf_counter()
+    out = a.decode_many(chunks); t2 = time.perf_counter()
+    px = W * H * F
+    res["many_chunk_calls_one_thread"] = {"chunks": n, "encode_s": round(t1 - t0, 3), "decode_s": round(t2 - t1, 3),
+                                          "encode_mpix_s": round(n * px / (t1 - t0) / 1e6, 1), "decode_mpix_s": round(n * px / (t2 - t1) / 1e6, 1),
+                                          "decoded_shape": list(out.shape)}
+    print("[probe] many-chunk calls:", res["many_chunk_calls_one_thread"], file=sys.stderr)
+    del rgb, chunks, out
 h = bench.synth_chunk(torch.device("cuda:0"), 0).reshape(-1).cpu()
 d = torch.empty(h.numel(), dtype=torch.uint8, device="cuda:0")
 torch.cuda.synchronize(); t3 = time.perf_counter(); d.copy_(h); torch.cuda.synchronize(); t4 = time.perf_counter()
