@@ -1,4 +1,4 @@
-"""Builds profiles/sq_counters.json from the four SQ counter passes of scripts/collect_sq_counters.sh (gpurun_out/sq/p1..p4:
+"""Builds profiles/sq_counters.json from the four SQ counter passes of scripts/collect_profiles.sh (gpurun_out/sq/p1..p4:
 one 1920x1080xF chunk, CDF 9/7 q=80, through scripts/profile_run.py F; pass F, default 64).  Counters are sums over the 8 XCDs and are
 averaged over the dispatches of a kernel.
 
