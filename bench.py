@@ -350,6 +350,10 @@ def main(argv=None) -> None:
         free_b, total_b = torch.cuda.mem_get_info(dev)
         if use_dist:
             fixed += 2 * max(world - 1, 1) * alc_stride                        # the root's receive ring
+            # RCCL creates its point-to-point channels (buffers per peer) at the first send / receive, i.e. AFTER the batch has
+            # taken its memory, and ranks cannot drop chunks one by one afterwards: keep 3 GiB back on every rank (three
+            # chunks of 341) rather than lose a multi-GPU run to an allocation failure inside the library
+            fixed += 3 << 30
         # (the capacities grow a little when another chunk's Y stream is longer than chunk 0's: 0.2 % of the .alc buffers kept back)
         margin = int(0.002 * 341 * alc_stride) + (64 << 20)
         B = int((free_b - fixed - margin) // per_chunk)
