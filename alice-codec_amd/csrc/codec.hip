@@ -496,6 +496,38 @@ int copy_to_host(void* dst, const void* d_src, size_t bytes, hipStream_t st) {
     return kOk;
 }
 
+// fn(i) for i in [0, n) on up to `width` helper threads bound to the calling thread's device (the copies of a many-chunk
+// call: every helper moves its chunks through pinned pieces of its own, so the CPU side of the copies runs side by side).
+// Returns the first failure, with its message, as this thread's error.
+template <typename Fn>
+int parallel_chunks(uint32_t n, uint32_t width, Fn fn) {
+    if (n <= 1 || width <= 1) {
+        for (uint32_t i = 0; i < n; ++i) TRY(fn(i));
+        return kOk;
+    }
+    const uint32_t T = std::min(width, n);
+    const int device = tl_device;
+    std::vector<int> code(T, kOk);
+    std::vector<std::string> msg(T);
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> th;
+    th.reserve(T);
+    for (uint32_t t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            clear_error();
+            tl_device = device;
+            int rc = ensure_device();
+            for (uint32_t i; rc == kOk && (i = next.fetch_add(1u)) < n;) rc = fn(i);
+            code[t] = rc;
+            if (rc != kOk) msg[t] = tl_msg;
+        });
+    for (auto& t : th) t.join();
+    for (uint32_t t = 0; t < T; ++t)
+        if (code[t] != kOk) return fail(code[t], msg[t]);
+    return kOk;
+}
+constexpr uint32_t kCopyThreads = 8;
+
 // records `ready` on st, runs the job through the hub, destroys the event
 int hub_run(HubTicket& t, HubJob& job, hipStream_t st) {
     HIP_TRY(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
@@ -2062,9 +2094,11 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
         int rc = d_rgb.alloc(chunk_bytes * B);
         if (rc == kOk) rc = encode_work_alloc(w, d, (int)B);
         if (rc != kOk) return undo(rc);
-        for (uint32_t i = 0; i < B; ++i)
-            if (hipMemcpyAsync(d_rgb.as<uint8_t>() + (size_t)i * chunk_bytes, rgb[first + i], chunk_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
-                return undo(fail(kDeviceError, "host to device copy failed"));
+        rc = parallel_chunks(B, chunk_bytes >= (4u << 20) ? kCopyThreads : 1u, [&](uint32_t i) {
+            HIP_TRY(hipMemcpyAsync(d_rgb.as<uint8_t>() + (size_t)i * chunk_bytes, rgb[first + i], chunk_bytes, hipMemcpyHostToDevice, st));
+            return (int)kOk;
+        });
+        if (rc != kOk) return undo(rc);
         for (int attempt = 0;; ++attempt) {
             rc = encode_launch(d_rgb.as<uint8_t>(), w, enc.quality, enc.wavelet, st, nullptr, (CapMode)attempt, &ticket);
             if (rc != kOk) return undo(rc);
@@ -2072,22 +2106,28 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
             if (rc == kOk) break;
             if (rc != -1 || attempt >= 2) return undo(rc == -1 ? fail(kInternal, "rANS output exceeded the worst-case bound") : rc);
         }
-        std::vector<uint8_t> hdr((size_t)kAlcHeaderBytes);
+        // all headers with one strided copy, then the payloads straight into the chunk objects, several at a time
+        std::vector<uint8_t> hdr((size_t)B * kAlcHeaderBytes);
+        if (hipMemcpy2DAsync(hdr.data(), kAlcHeaderBytes, w.alc.p, w.alc_stride, kAlcHeaderBytes, B, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return undo(fail(kDeviceError, "device to host copy failed"));
         for (uint32_t i = 0; i < B; ++i) {
             const uint64_t payload = res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
-            const uint8_t* d_alc = w.alc.as<uint8_t>() + (size_t)i * w.alc_stride;
-            if (hipMemcpyAsync(hdr.data(), d_alc, hdr.size(), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-                return undo(fail(kDeviceError, "device to host copy failed"));
             EncodedChunk* c = new (std::nothrow) EncodedChunk();
             uint64_t tot = 0;
-            if (!c || parse_alc_header(hdr.data(), hdr.size() + payload, *c, &tot) != kOk || tot != payload) {
+            if (!c || parse_alc_header(hdr.data() + (size_t)i * kAlcHeaderBytes, kAlcHeaderBytes + payload, *c, &tot) != kOk || tot != payload) {
                 delete c;
                 return undo(fail(kInternal, "device header/payload length mismatch"));
             }
             *out[first + i] = c;   // (undo() deletes it from here on)
-            c->data.resize((size_t)payload);
-            if (copy_to_host(c->data.data(), d_alc + kAlcHeaderBytes, (size_t)payload, st) != kOk) return undo(tl_err);
         }
+        rc = parallel_chunks(B, w.alc_stride >= (4u << 20) ? kCopyThreads : 1u, [&](uint32_t i) {
+            EncodedChunk* c = *out[first + i];
+            const uint64_t payload = res[3 * i].len + res[3 * i + 1].len + res[3 * i + 2].len;
+            c->data.resize((size_t)payload);
+            return copy_to_host(c->data.data(), w.alc.as<uint8_t>() + (size_t)i * w.alc_stride + kAlcHeaderBytes, (size_t)payload, st);
+        });
+        if (rc != kOk) return undo(rc);
     }
     return kOk;
 }
@@ -2129,7 +2169,8 @@ static int decode_chunks_on_device(const std::vector<const EncodedChunk*>& chunk
         TRY(decode_work_alloc(w, d, (int)B));
         TRY(decode_launch(hdrs, pay, w, dst, st, nullptr, &ticket));
         TRY(decode_collect(w, st));
-        for (uint32_t i = 0; i < B; ++i) TRY(copy_to_host(rgb_out[first + i], dst[i], chunk_bytes, st));
+        TRY(parallel_chunks(B, chunk_bytes >= (4u << 20) ? kCopyThreads : 1u,
+                            [&](uint32_t i) { return copy_to_host(rgb_out[first + i], dst[i], chunk_bytes, st); }));
     }
     return kOk;
 }
