@@ -67,8 +67,6 @@ void clear_error() { tl_err = kOk; tl_msg.clear(); }
 // ------------------------------------------------------------------------------------------
 
 thread_local int tl_device = -1;         // -1: not chosen yet (device 0 on first use)
-thread_local hipStream_t tl_stream = nullptr;
-thread_local int tl_stream_device = -1;
 // stream the work of the current entry point runs on: buffers allocated meanwhile remember it and drain it before they
 // go back to the pool (an error return may leave kernels in flight on them)
 thread_local hipStream_t tl_scope_stream = nullptr;
@@ -102,17 +100,8 @@ int ensure_device() {
     return kOk;
 }
 
-int get_stream(hipStream_t* out) {
-    int rc = ensure_device();
-    if (rc) return rc;
-    if (!tl_stream || tl_stream_device != tl_device) {
-        HIP_TRY(hipStreamCreateWithFlags(&tl_stream, hipStreamNonBlocking));
-        tl_stream_device = tl_device;
-    }
-    *out = tl_stream;
-    tl_scope_stream = tl_stream;
-    return kOk;
-}
+// the stream this thread's host-side work goes to: one of the chain hub's shared short streams (defined below ChainHub)
+int get_stream(hipStream_t* out);
 
 // Size-bucketed cache of device allocations.  hipFree waits for EVERY kernel running on the device -- with other threads'
 // chains in flight that is seconds (64 host threads through alice_codec_encode64 took 49 s instead of 6 while the cache
@@ -529,15 +518,39 @@ int parallel_chunks(uint32_t n, uint32_t width, Fn fn) {
 constexpr uint32_t kCopyThreads = 8;
 
 // records `ready` on st, runs the job through the hub, destroys the event
-int hub_run(HubTicket& t, HubJob& job, hipStream_t st) {
+int hub_run(ChainHub* hub, HubTicket* t, HubJob& job, hipStream_t st) {
     HIP_TRY(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
     int rc = kOk;
     if (hipEventRecord(job.ready, st) != hipSuccess) rc = fail(kDeviceError, "hipEventRecord failed");
-    t.arrived();
-    if (rc == kOk) rc = t.hub->run(job);
+    if (t) t->arrived();
+    if (rc == kOk) rc = hub->run(job);
     (void)hipEventDestroy(job.ready);
     job.ready = nullptr;
     return rc;
+}
+int hub_run(HubTicket& t, HubJob& job, hipStream_t st) { return hub_run(t.hub, &t, job, st); }
+
+// Every host entry point works on a short stream of its device's hub: the library owns kHubShort + kHubLanes streams per
+// device and none per calling thread.
+int get_stream(hipStream_t* out) {
+    TRY(ensure_device());
+    ChainHub* hub = ChainHub::of_device(tl_device);
+    if (!hub->ok()) return fail(kDeviceError, "the streams of the chain hub could not be created");
+    *out = hub->short_stream();
+    tl_scope_stream = *out;
+    return kOk;
+}
+
+// The chains of a stage-level call (RansEncoder / RansDecoder objects, the one-shot and the interleaved calls): they may run
+// for seconds, so they too leave with the hub's merged launches instead of sitting on a short stream.  `st`: the short
+// stream the call's other work is on (the chains' inputs are complete at this point of it).
+int stage_chains(hipStream_t st, std::vector<RansEncodeDesc>&& enc, std::vector<RansDecodeDesc>&& dec, uint64_t symbols_per_chain) {
+    HubJob job;
+    job.encode = !enc.empty();
+    job.enc = std::move(enc);
+    job.dec = std::move(dec);
+    job.seconds = (double)symbols_per_chain * (job.encode ? 21e-9 : 39e-9);
+    return hub_run(ChainHub::of_device(tl_device), nullptr, job, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -839,6 +852,8 @@ int encode_launch(const uint8_t* d_rgb, EncodeWork& w, uint8_t quality, int wave
             e.region = w.alc.as<uint8_t>() + (size_t)(c / 3) * w.alc_stride + kStreamHead + (g == 0 ? 0ull : (g == 1 ? w.cap[0] : w.cap[0] + w.cap[1]));
             e.cap = w.cap[g];
             e.result = w.results.as<RansResult>() + c;
+            e.x_init = kRansL;
+            e.keep_open = 0u;
         }
         job.seconds = (double)d.padded * 21e-9;
         TRY(hub_run(*hub, job, st));
@@ -1632,7 +1647,8 @@ uint8_t* alice_codec_rans_encode(const uint8_t* symbols, uint64_t n, const uint1
     if (n && !ok(hipMemcpyAsync(ds.p, symbols, n, hipMemcpyHostToDevice, st))) return nullptr;
     if (!ok(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st)) || !ok(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st))) return nullptr;
     launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
-    launch_rans_encode(ds.as<uint8_t>(), n, n, dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), 1, st);
+    if (stage_chains(st, {RansEncodeDesc{ds.as<uint8_t>(), n, dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), kRansL, 0u}}, {}, n) != kOk)
+        return nullptr;
     if (!ok(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) return nullptr;
     if (res.flags & kTableDiverges) { fail(kReferenceDiverges, "symbol with table frequency 0 encoded"); return nullptr; }
     if (res.flags & (kRansOverflow | kRansInternal)) { fail(kInternal, "rANS encode failed"); return nullptr; }
@@ -1657,9 +1673,9 @@ int alice_codec_rans_decode(const uint8_t* bytes, uint64_t len, const uint16_t c
     HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
     RansDecodeDesc desc{din.as<uint8_t>(), len, dout.as<uint8_t>(), n, dt.as<RansTable>()};
-    HIP_TRY(hipMemcpyAsync(ddesc.p, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    desc.result = dres.as<RansResult>();
     launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
-    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 1, st);
+    TRY(stage_chains(st, {}, {desc}, n));
     RansResult res{};
     HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(symbols, dout.p, n, hipMemcpyDeviceToHost, st));
@@ -1692,8 +1708,7 @@ int alice_codec_rans_encoder_encode_symbols(AliceRansEncoder* e, const uint8_t* 
     HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
     launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
-    launch_rans_encode(ds.as<uint8_t>(), n, n, dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), 1, st,
-                       0, 0, 0xFFFFFFFFu, 0, 0, e->state, true);
+    TRY(stage_chains(st, {RansEncodeDesc{ds.as<uint8_t>(), n, dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), e->state, 1u}}, {}, n));
     RansResult res{};
     HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1775,9 +1790,9 @@ int alice_codec_rans_decoder_decode_n(AliceRansDecoder* d, uint64_t n, const uin
     HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
     RansDecodeDesc desc{d->d_input.as<uint8_t>(), len, dout.as<uint8_t>(), n, dt.as<RansTable>(), 1u, d->state, d->pos};
-    HIP_TRY(hipMemcpyAsync(ddesc.p, &desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    desc.result = dres.as<RansResult>();
     launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
-    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 1, st);
+    TRY(stage_chains(st, {}, {desc}, n));
     RansResult res{};
     HIP_TRY(hipMemcpyAsync(&res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(symbols, dout.p, n, hipMemcpyDeviceToHost, st));
@@ -1921,9 +1936,7 @@ uint8_t* alice_codec_rans_encode_interleaved(const uint8_t* symbols, uint64_t n,
     hipStream_t st;
     if (get_stream(&st)) return nullptr;
     uint64_t cnt[4];
-    unsigned split = 0;
     for (int j = 0; j < 4; ++j) cnt[j] = (n + 3 - j) / 4;        // :423-425
-    for (int j = 0; j < 4; ++j) split += cnt[j] == cnt[0];
     if (cnt[0] > 0xFFFFFFFFull) { fail(kDimensionOverflow, "symbol count does not fit the u32 header field"); return nullptr; }
     const uint64_t stride = round_up(cnt[0] + 16, 256);
     const uint64_t cap = round_up(2 * cnt[0] + 4 + 64 + 64, 256);
@@ -1935,8 +1948,13 @@ uint8_t* alice_codec_rans_encode_interleaved(const uint8_t* symbols, uint64_t n,
     if (!ok(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st)) || !ok(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st))) return nullptr;
     launch_split4(ds.as<uint8_t>(), n, d4.as<uint8_t>(), stride, st);
     for (int j = 0; j < 4; ++j) launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>() + j, st);
-    launch_rans_encode(d4.as<uint8_t>(), stride, cnt[0], dt.as<RansTable>(), dout.as<uint8_t>(), cap, dres.as<RansResult>(), 4, st,
-                       0, 0, split);
+    {
+        std::vector<RansEncodeDesc> enc(4);
+        for (int j = 0; j < 4; ++j)
+            enc[j] = RansEncodeDesc{d4.as<uint8_t>() + (size_t)j * stride, cnt[j], dt.as<RansTable>() + j, dout.as<uint8_t>() + (size_t)j * cap, cap,
+                                    dres.as<RansResult>() + j, kRansL, 0u};
+        if (stage_chains(st, std::move(enc), {}, cnt[0]) != kOk) return nullptr;
+    }
     RansResult res[4];
     if (!ok(hipMemcpyAsync(res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st)) || !ok(hipStreamSynchronize(st))) return nullptr;
     uint64_t total = 32;
@@ -1999,15 +2017,15 @@ int alice_codec_rans_decode_interleaved(const uint8_t* bytes, uint64_t len, cons
     HIP_TRY(hipMemcpyAsync(din.p, bytes, len, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dc.p, cum_freq, 512, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(df.p, freq, 512, hipMemcpyHostToDevice, st));
-    RansDecodeDesc desc[4];
+    std::vector<RansDecodeDesc> desc(4);
     uint64_t off = 32;
     for (int j = 0; j < 4; ++j) {
         desc[j] = RansDecodeDesc{din.as<uint8_t>() + off, slen[j], d4.as<uint8_t>() + (size_t)j * stride, need[j], dt.as<RansTable>()};
+        desc[j].result = dres.as<RansResult>() + j;
         off += slen[j];
     }
-    HIP_TRY(hipMemcpyAsync(ddesc.p, desc, sizeof(desc), hipMemcpyHostToDevice, st));
     launch_rans_table_from_arrays(dc.as<uint16_t>(), df.as<uint16_t>(), dt.as<RansTable>(), st);
-    launch_rans_decode(ddesc.as<RansDecodeDesc>(), dres.as<RansResult>(), 4, st);
+    TRY(stage_chains(st, {}, std::move(desc), mx));
     launch_merge4(d4.as<uint8_t>(), stride, need, cnt, dout.as<uint8_t>(), n, st);
     RansResult res[4];
     HIP_TRY(hipMemcpyAsync(res, dres.p, sizeof(res), hipMemcpyDeviceToHost, st));

@@ -58,6 +58,8 @@ struct RansEncodeDesc {
     uint8_t* region;          // the stream is written back to front into [region, region + cap)
     unsigned long long cap;
     RansResult* result;
+    uint32_t x_init;          // kRansL for a fresh encoder; a RansEncoder object between calls brings its state
+    uint32_t keep_open;       // 1: leave the four state bytes of finish() unwritten (the object lives on)
 };
 
 // ---- rans.hip ----
@@ -86,7 +88,7 @@ void launch_split4(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t str
 void launch_merge4(const uint8_t* d_in, uint64_t stride, const uint64_t have[4], const uint64_t count[4], uint8_t* d_out,
                    uint64_t n_out, hipStream_t st);
 void launch_rans_decode(const RansDecodeDesc* d_descs, RansResult* d_results, int n_chains, hipStream_t st);
-// chains described one by one (fresh encoders: state 2^23, finish() bytes written); every desc names its result
+// chains described one by one; every desc names its result, its start state and whether the stream is finished
 void launch_rans_encode_descs(const RansEncodeDesc* d_descs, int n_chains, hipStream_t st);
 // what the runtime reports for the one-chain-per-SIMD instances: out[0..2] = encoder registers per lane (VGPR + AGPR),
 // static LDS bytes, workgroups per CU it would co-schedule; out[3..5] = decoder.  False when a query failed.

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const uint8_t* __restri
     if (descs) {   // a merged launch (launch_rans_encode_descs): every chain spelled out
         const RansEncodeDesc ds = descs[chain];
         sym = ds.sym; n = ds.n; tbl = ds.table; region = ds.region; cap = ds.cap; res = ds.result;
+        x_init = ds.x_init; keep_open = ds.keep_open;
     }
     uint8_t* const out_end = region + cap;
     // lanes that have nothing to emit store to a private byte at the unused front of the region instead
