@@ -2248,7 +2248,7 @@ int alice_codec_decode_many(const EncodedChunk* const* chunks, uint32_t n_chunks
 }
 
 // ---- the same over several GPUs of the node: chunk k goes to devices[k mod n_devices] (64-frame chunks are independent
-// bitstreams, src/pipeline.rs:461-497: no cross-chunk state), one host thread and one stream per listed device, every
+// bitstreams, src/pipeline.rs:461-497: no cross-chunk state), one host thread per listed device, every
 // device moves its own chunks over its own PCIe link, results land in the caller's arrays in chunk order ----
 
 int alice_codec_many_devices_plan(uint32_t n_chunks, const int* devices, uint32_t n_devices, int* device_of_chunk) {
