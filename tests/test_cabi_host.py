@@ -239,3 +239,30 @@ def test_many_devices_validate_before_touching_a_gpu(codec):
     assert lib.alice_codec_encode_many_devices(enc, buf, 0, 4, 4, 2, 0, devs, 2, out) == 0       # no chunks: nothing to do
     assert lib.alice_codec_decode_many_devices(None, 1, devs, 2, buf, 10) == 9
     lib.alice_codec_encoder_destroy(enc)
+
+
+def test_adopted_result_buffers_are_freed_once_with_the_last_view(codec):
+    """FrameDecoder.decode hands out the library's own buffer (no 398 MB copy): the array's base owns it and gives it to
+    the free function when the last view dies, not before and not twice."""
+    import gc
+    libc = C.CDLL("libc.so.6")
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    freed = []
+
+    def free(p, n):
+        freed.append((p, n))
+        libc.free(C.c_void_p(p))
+    p = libc.malloc(1000)
+    C.memset(p, 7, 1000)
+    a = codec._adopt(p, 1000, free)
+    assert a.dtype == np.uint8 and a.size == 1000 and int(a.sum()) == 7000 and a.flags.writeable
+    view = a[100:200]
+    del a
+    gc.collect()
+    assert freed == [] and int(view.sum()) == 700
+    del view
+    gc.collect()
+    assert freed == [(p, 1000)]
+    q = libc.malloc(1)
+    assert codec._adopt(q, 0, free).size == 0 and freed[-1] == (q, 0)     # an empty result: released at once
