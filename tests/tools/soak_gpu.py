@@ -3,7 +3,10 @@ oracle -- whole chunks of random shape / wavelet / quality / content with random
 blobs with corrupted payloads and headers (both sides must agree on the decoded bytes or both must refuse), random call
 sequences on the stateful rANS coders, batches of random size.  Prints every mismatch with the seed that reproduces it.
 
-    python tests/tools/soak_gpu.py [seconds, default 300] [first seed, default 1]"""
+    python tests/tools/soak_gpu.py [seconds, default 300] [first seed, default 1] [threads, default 1]
+
+With threads > 1 the cases run concurrently (whole chunks and coder sequences; the process-wide test tunings stay at their
+defaults, batches are left out): the chain hub's merged launches under a random mix of callers."""
 import os
 import sys
 import time
@@ -15,6 +18,7 @@ import alice_codec_amd as a  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+n_threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lib = a.load_library()
 bad = []
 counts = {}
@@ -58,8 +62,11 @@ def chunk_case(rng, seed):
     band = int(rng.choice([0, 64, 96, 200, 1024, 1024 * 1024]))
     radius = int(rng.choice([2048, 2048, 700, 64, 3, 1]))
     rgb, ck = content(rng, w, h, f)
-    lib.alice_codec_test_set_tuning(band)
-    lib.alice_codec_test_set_value_table_radius(radius)
+    if n_threads == 1:          # (process-wide hooks: not while other threads are inside calls)
+        lib.alice_codec_test_set_tuning(band)
+        lib.alice_codec_test_set_value_table_radius(radius)
+    else:
+        band, radius = -1, -1
     tag = (seed, w, h, f, k, q, band, radius, ck)
     try:
         ref = o.encode(rgb, w, h, f, q, k)
@@ -183,21 +190,47 @@ def batch_case(rng, seed):
 
 t0 = time.time()
 seed = seed0
-while time.time() - t0 < budget:
+
+
+def one_case(seed):
     rng = np.random.default_rng(seed)
     r = seed % 10
     try:
         if r < 6:
             chunk_case(rng, seed)
-        elif r < 9:
+        elif r < 9 or n_threads > 1:
             coder_case(rng, seed)
         else:
             batch_case(rng, seed)
     except Exception as e:   # noqa: BLE001
         note("exception", False, ("exception", seed, repr(e)[:300]))
-    seed += 1
-    if (seed - seed0) % 50 == 0:
-        print(f"[soak] {seed - seed0} cases, {time.time() - t0:.0f} s, {len(bad)} mismatches, {counts}", flush=True)
+
+
+if n_threads > 1:
+    import itertools
+    import threading
+    ticket = itertools.count(seed0)
+    lock = threading.Lock()
+
+    def worker():
+        a.set_device(0)
+        while time.time() - t0 < budget:
+            with lock:
+                sd = next(ticket)
+            one_case(sd)
+    th = [threading.Thread(target=worker) for _ in range(n_threads)]
+    [t.start() for t in th]
+    while any(t.is_alive() for t in th):
+        time.sleep(15)
+        print(f"[soak] {n_threads} threads, {time.time() - t0:.0f} s, {len(bad)} mismatches, {counts}", flush=True)
+    [t.join() for t in th]
+    seed = next(ticket)
+else:
+    while time.time() - t0 < budget:
+        one_case(seed)
+        seed += 1
+        if (seed - seed0) % 50 == 0:
+            print(f"[soak] {seed - seed0} cases, {time.time() - t0:.0f} s, {len(bad)} mismatches, {counts}", flush=True)
 lib.alice_codec_test_set_tuning(1024 * 1024)
 lib.alice_codec_test_set_value_table_radius(2048)
 print(f"[soak] done: seeds {seed0}..{seed - 1}, {counts}, mismatches: {len(bad)}")
