@@ -151,6 +151,7 @@ public:
         free_.clear();
         cached_ = 0;
     }
+    size_t cached() { std::lock_guard<std::mutex> g(mu_); return cached_; }
 private:
     static size_t bucket(size_t bytes) {
         if (bytes < 256) bytes = 256;
@@ -311,6 +312,29 @@ public:
         thread_local unsigned mine = next.fetch_add(1u);
         return short_[mine % kHubShort];
     }
+    // Admission: the whole-chunk calls in flight together must fit the device.  A call states what it is about to allocate
+    // and waits here while the calls already inside hold too much (a call alone always enters); without this a thread pool
+    // larger than the memory allows would turn the surplus calls into out-of-memory errors instead of a queue.
+    void admit(size_t bytes) {
+        std::unique_lock<std::mutex> lk(adm_mu_);
+        adm_cv_.wait(lk, [&] {
+            if (in_flight_ == 0) {
+                // nobody inside: what the device has free now plus what the pool would hand back is the budget (90 % of it)
+                if (!budget_fixed_) {
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = size_t(16) << 30; }
+                    budget_ = (free_b + pool().cached()) / 10 * 9;
+                }
+                return true;
+            }
+            return in_flight_ + bytes <= budget_;
+        });
+        in_flight_ += bytes;
+        if (getenv("ALICE_CODEC_DEBUG"))
+            fprintf(stderr, "[alice] hub: admitted %.2f GB, %.2f GB in flight of a budget of %.2f GB\n", bytes / 1e9, in_flight_ / 1e9, budget_ / 1e9);
+    }
+    void leave(size_t bytes) { { std::lock_guard<std::mutex> g(adm_mu_); in_flight_ -= std::min(in_flight_, bytes); } adm_cv_.notify_all(); }
+    void set_budget(size_t bytes) { { std::lock_guard<std::mutex> g(adm_mu_); budget_ = bytes; budget_fixed_ = bytes != 0; } adm_cv_.notify_all(); }
     void announce() { std::lock_guard<std::mutex> g(mu_); ++expected_; }
     void arrived_or_gone() { { std::lock_guard<std::mutex> g(mu_); if (expected_ > 0) --expected_; } cv_.notify_all(); }
 
@@ -410,6 +434,10 @@ private:
     int expected_ = 0;
     bool leader_active_ = false;
     bool ok_ = true;
+    std::mutex adm_mu_;
+    std::condition_variable adm_cv_;
+    size_t in_flight_ = 0, budget_ = 0;   // bytes; the budget is re-measured whenever a call enters an idle hub
+    bool budget_fixed_ = false;           // set by the test hook
     int next_lane_ = 0;
     hipStream_t short_[kHubShort] = {nullptr};
     Lane lanes_[kHubLanes];
@@ -420,10 +448,14 @@ struct HubTicket {
     ChainHub* hub = nullptr;
     bool counted = false;
     hipStream_t st = nullptr;
-    int open() {
+    size_t admitted = 0;
+    // device_bytes: what the call is about to allocate on the device, roughly (see ChainHub::admit)
+    int open(size_t device_bytes) {
         TRY(ensure_device());
         hub = ChainHub::of_device(tl_device);
         if (!hub->ok()) return fail(kDeviceError, "the streams of the chain hub could not be created");
+        hub->admit(device_bytes);
+        admitted = device_bytes;
         hub->announce();
         counted = true;
         st = hub->short_stream();
@@ -431,8 +463,14 @@ struct HubTicket {
         return kOk;
     }
     void arrived() { if (counted) { counted = false; hub->arrived_or_gone(); } }
-    ~HubTicket() { arrived(); tl_scope_stream = nullptr; }
+    ~HubTicket() { arrived(); if (hub) hub->leave(admitted); tl_scope_stream = nullptr; }
 };
+// device memory of an encode / a decode of n chunks of shape d (inputs or pixels, symbols, .alc at a byte per symbol, the
+// transform scratch): the figure admission works with
+size_t encode_device_bytes(const ChunkDims& d, uint64_t n) { return (size_t)(n * (d.n_pixels * 3 + d.padded * 6) + forward_scratch_bytes(d)); }
+size_t decode_device_bytes(const ChunkDims& d, uint64_t n, uint64_t payload) {
+    return (size_t)(n * (d.n_pixels * 3 + d.padded * 3) + payload + inverse_scratch_bytes(d, false));
+}
 
 // Large device-to-host copies into the caller's pageable memory.  hipMemcpyAsync to pageable memory goes through the
 // runtime's own staging at about 3 GB/s and keeps the stream busy meanwhile (110 MB of .alc: 37 ms; 64 threads' decoded
@@ -1054,7 +1092,7 @@ int encode_host(const FrameEncoder& enc, const uint8_t* rgb, uint64_t rgb_len, u
     if (d.padded > 0xFFFFFFFFull) return fail(kDimensionOverflow, "padded pixel count does not fit the header's u32 num_symbols");
 
     HubTicket ticket;
-    TRY(ticket.open());
+    TRY(ticket.open(encode_device_bytes(d, 1)));
     const hipStream_t st = ticket.st;
     DevBuf d_rgb;
     TRY(d_rgb.alloc(rgb_len));
@@ -1101,7 +1139,7 @@ int decode_host(const EncodedChunk& c, uint8_t** out, uint64_t* out_len) {
     *out = nullptr; *out_len = 0;
     if (d.n_pixels == 0) { *out = host_result_alloc(0); return *out ? kOk : fail(kOutOfMemory, "out of host memory"); }
     HubTicket ticket;
-    TRY(ticket.open());
+    TRY(ticket.open(decode_device_bytes(d, 1, c.data.size())));
     const hipStream_t st = ticket.st;
     DevBuf d_payload, d_rgb;
     TRY(d_payload.alloc(c.data.size() + 16));
@@ -2098,12 +2136,13 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
     const uint32_t n = (uint32_t)rgb.size();
     for (uint32_t i = 0; i < n; ++i) *out[i] = nullptr;
     if (!n) return kOk;
+    TRY(ensure_device());
+    const uint32_t per_pass = chunks_that_fit(d, n);
     HubTicket ticket;
-    TRY(ticket.open());
+    TRY(ticket.open(encode_device_bytes(d, per_pass)));
     const hipStream_t st = ticket.st;
     auto undo = [&](int rc) { for (uint32_t k = 0; k < n; ++k) { delete *out[k]; *out[k] = nullptr; } return rc; };
     const uint64_t chunk_bytes = d.n_pixels * 3;
-    const uint32_t per_pass = chunks_that_fit(d, n);
     for (uint32_t first = 0; first < n; first += per_pass) {
         const uint32_t B = std::min(per_pass, n - first);
         DevBuf d_rgb;
@@ -2154,11 +2193,14 @@ static int encode_chunks_on_device(const FrameEncoder& enc, const std::vector<co
 static int decode_chunks_on_device(const std::vector<const EncodedChunk*>& chunks, const ChunkDims& d, const std::vector<uint8_t*>& rgb_out) {
     const uint32_t n = (uint32_t)chunks.size();
     if (!n || d.n_pixels == 0) return kOk;
+    TRY(ensure_device());
+    const uint32_t per_pass = chunks_that_fit(d, n);
+    uint64_t max_payload = 0;
+    for (const EncodedChunk* c : chunks) max_payload = std::max<uint64_t>(max_payload, c->data.size());
     HubTicket ticket;
-    TRY(ticket.open());
+    TRY(ticket.open(decode_device_bytes(d, per_pass, (uint64_t)per_pass * (max_payload + 512))));
     const hipStream_t st = ticket.st;
     const uint64_t chunk_bytes = d.n_pixels * 3;
-    const uint32_t per_pass = chunks_that_fit(d, n);
     for (uint32_t first = 0; first < n; first += per_pass) {
         const uint32_t B = std::min(per_pass, n - first);
         std::vector<EncodedChunk> hdrs(B);
@@ -2476,6 +2518,12 @@ int alice_codec_dev_rans_decode(const void* d_stream, uint64_t len, const uint32
 
 void alice_codec_test_set_tuning(long band_kb) { set_transform_tuning(band_kb); }
 void alice_codec_test_set_value_table_radius(int r) { set_value_table_radius(r); }
+int alice_codec_test_set_admission_budget(uint64_t bytes) {
+    clear_error();
+    TRY(ensure_device());
+    ChainHub::of_device(tl_device)->set_budget((size_t)bytes);
+    return kOk;
+}
 
 int alice_codec_test_chain_occupancy(uint32_t out[6]) {
     clear_error();

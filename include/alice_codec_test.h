@@ -42,6 +42,13 @@ void alice_codec_test_set_tuning(long band_kb);
  * and the boundary; results never depend on it. */
 void alice_codec_test_set_value_table_radius(int r);
 
+/* Admission budget of the calling thread's device (csrc/codec.hip, ChainHub::admit): whole-chunk host calls state the
+ * device memory they are about to allocate and wait while the calls already in flight hold more than the budget allows
+ * (a call alone always enters).  Default: 90 % of what is free (device + the library's cache) whenever a call enters an
+ * idle hub; 0 restores that.  The suite
+ * shrinks it so that a handful of small calls already queue; results never depend on it. */
+int alice_codec_test_set_admission_budget(uint64_t bytes);
+
 /* Resident chain kernels: what the runtime reports for the one-chain-per-SIMD instances of the rANS kernels.
  * out[0..2] = encoder: registers per lane (VGPR + AGPR, as allocated), static LDS bytes, workgroups per CU the runtime
  * would co-schedule; out[3..5] = the same for the decoder.  The exclusive instances must report at most 4 workgroups

@@ -109,3 +109,29 @@ def test_overflow_retry_inside_a_merged_launch(gpu_codec, oracle_mod):
         finally:
             lib.alice_codec_test_force_first_cap(0)
     assert run_threads([lambda i=i: work(i) for i in range(6)]) == []
+
+
+def test_admission_queues_calls_instead_of_failing_them(gpu_codec, oracle_mod):
+    """More concurrent calls than the admission budget holds wait their turn (alice_codec_test_set_admission_budget: a budget
+    of one byte admits one call at a time, a budget of three calls' worth three); every call still succeeds with the oracle's
+    bytes.  0 restores the measured budget."""
+    w, h, f = 96, 64, 8
+    import ctypes as C
+    lib = gpu_codec.load_library()
+    lib.alice_codec_test_set_admission_budget.argtypes = [C.c_uint64]
+    rgbs = [smooth(w, h, f, seed=700 + i) for i in range(10)]
+    refs = [oracle_mod.encode(r, w, h, f, 80, 1) for r in rgbs]
+    per_call = w * h * f * 3 * 4
+    try:
+        for budget in (1, 3 * per_call):
+            assert lib.alice_codec_test_set_admission_budget(budget) == 0
+            out = [None] * 10
+
+            def work(i):
+                c = gpu_codec.FrameEncoder.with_wavelet(80, gpu_codec.WaveletType.Cdf97).encode(rgbs[i], w, h, f)
+                out[i] = (c.to_bytes(), np.array(gpu_codec.FrameDecoder().decode(c)))
+            assert run_threads([lambda i=i: work(i) for i in range(10)]) == []
+            for i in range(10):
+                assert out[i][0] == refs[i] and np.array_equal(out[i][1], oracle_mod.decode(refs[i])), (budget, i)
+    finally:
+        lib.alice_codec_test_set_admission_budget(0)
