@@ -317,7 +317,9 @@ public:
     // larger than the memory allows would turn the surplus calls into out-of-memory errors instead of a queue.
     void admit(size_t bytes) {
         std::unique_lock<std::mutex> lk(adm_mu_);
+        const uint64_t my_turn = next_turn_++;   // first come, first admitted: a large call is not starved by a stream of small ones
         adm_cv_.wait(lk, [&] {
+            if (my_turn != serving_) return false;
             if (in_flight_ == 0) {
                 // nobody inside: what the device has free now plus what the pool would hand back is the budget (90 % of it)
                 if (!budget_fixed_) {
@@ -330,6 +332,8 @@ public:
             return in_flight_ + bytes <= budget_;
         });
         in_flight_ += bytes;
+        ++serving_;
+        adm_cv_.notify_all();
         if (getenv("ALICE_CODEC_DEBUG"))
             fprintf(stderr, "[alice] hub: admitted %.2f GB, %.2f GB in flight of a budget of %.2f GB\n", bytes / 1e9, in_flight_ / 1e9, budget_ / 1e9);
     }
@@ -438,6 +442,7 @@ private:
     std::condition_variable adm_cv_;
     size_t in_flight_ = 0, budget_ = 0;   // bytes; the budget is re-measured whenever a call enters an idle hub
     bool budget_fixed_ = false;           // set by the test hook
+    uint64_t next_turn_ = 0, serving_ = 0;
     int next_lane_ = 0;
     hipStream_t short_[kHubShort] = {nullptr};
     Lane lanes_[kHubLanes];
